@@ -1,0 +1,404 @@
+/*
+ * infl_host.c -- host side of the inflate API (plain C, like the reference's
+ * host code).  It owns the opaque stream object and the input piece list and
+ * hands complete inputs to the GPU engine; it contains no decoder.
+ *
+ * Functions of the reference this file replaces:
+ *   infl_init            src/infl/infl.c:1677-1695
+ *   infl_include         src/infl/mem.c:114-216
+ *   infl_reset_pool      src/infl/mem.c:219-232
+ *   infl_reset           src/infl/mem.c:257-275
+ *   infl_resize_output   src/infl/mem.c:277-288
+ *   infl_output_pos      src/infl/mem.c:290-294
+ *   infl_input_pos       src/infl/mem.c:296-329
+ *   infl_destroy         src/infl/mem.c:331-361
+ *   infl                 src/infl/infl.c:1507-1675 (dispatch only; decode is on the GPU)
+ *   infl_stream          src/infl/stream.c:468-794
+ * plus infl_many(), the deferred form of infl() over many streams.
+ *
+ * Input ownership follows the reference: a piece of at most 8 KiB
+ * (UNZ_CHUNK_APPEND_THRESHOLD, src/common.h:46) is copied and coalesced into
+ * 32 KiB pages owned by the stream (src/common.h:45); a larger piece is
+ * borrowed by pointer and must stay valid until infl() has returned.  Where the
+ * reference stops copying once its 32-page pool is used up (mem.c:152-155) this
+ * implementation keeps allocating pages, which is the safer superset.
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/defl/infl.h"
+#include "../../include/defl/infl_batch.h"
+#include "infl_device.h"
+
+#define PAGE_SIZE        32768u   /* UNZ_CHUNK_PAGE_SIZE,        src/common.h:45 */
+#define APPEND_THRESHOLD 8192u    /* UNZ_CHUNK_APPEND_THRESHOLD, src/common.h:46 */
+
+typedef struct piece_t {
+  const uint8_t *p;
+  uint32_t       len;
+  int32_t        page;            /* index into pages[] or -1 when borrowed */
+} piece_t;
+
+struct unz__stream_t {
+  uint8_t  *dst;
+  uint32_t  dstlen;
+  uint32_t  dstpos;
+  uint32_t  inpos;
+  int       flags;
+
+  piece_t  *pieces;
+  size_t    npieces, cappieces;
+  size_t    srclen;               /* sum of piece lengths */
+
+  uint8_t **pages;                /* owned 32 KiB pages, kept across resets */
+  size_t    npages, cappages;
+  size_t    pages_used;
+  uint32_t  page_fill;            /* bytes used in the page being appended to */
+  int       appending;            /* last piece is an owned page with room left */
+
+  uint8_t  *gather;               /* contiguous staging for multi-piece inputs */
+  size_t    gather_cap;
+
+  int       stream_done;          /* infl_stream() reached the final block */
+};
+
+static void
+warn_no_device(void) {
+  static int warned;
+  if (!warned) {
+    warned = 1;
+    fprintf(stderr, "defl: no usable HIP device; the inflate engine has no CPU decoder\n");
+  }
+}
+
+UNZ_EXPORT infl_stream_t *
+infl_init(void * __restrict dst, uint32_t dstlen, int flags) {
+  infl_stream_t *st = (infl_stream_t *)calloc(1, sizeof(*st));
+  if (!st)
+    return NULL;
+  st->dst    = (uint8_t *)dst;
+  st->dstlen = dstlen;
+  st->flags  = flags;
+  return st;
+}
+
+UNZ_EXPORT void
+infl_reset_pool(infl_stream_t * __restrict st) {
+  if (!st)
+    return;
+  st->npieces    = 0;
+  st->srclen     = 0;
+  st->pages_used = 0;
+  st->page_fill  = 0;
+  st->appending  = 0;
+}
+
+UNZ_EXPORT void
+infl_reset(infl_stream_t * __restrict st, void * __restrict dst, uint32_t dstlen, int flags) {
+  if (!st)
+    return;
+  infl_reset_pool(st);
+  st->dst         = (uint8_t *)dst;
+  st->dstlen      = dstlen;
+  st->dstpos      = 0;
+  st->inpos       = 0;
+  st->flags       = flags;
+  st->stream_done = 0;
+}
+
+UNZ_EXPORT int
+infl_resize_output(infl_stream_t * __restrict st, void * __restrict dst, uint32_t dstlen) {
+  if (!st || !dst || dstlen < st->dstpos)
+    return UNZ_ERR;
+  st->dst    = (uint8_t *)dst;
+  st->dstlen = dstlen;
+  return UNZ_OK;
+}
+
+UNZ_EXPORT uint32_t
+infl_output_pos(const infl_stream_t * __restrict st) {
+  return st ? st->dstpos : 0u;
+}
+
+UNZ_EXPORT uint32_t
+infl_input_pos(const infl_stream_t * __restrict st) {
+  return st ? st->inpos : 0u;
+}
+
+UNZ_EXPORT void
+infl_destroy(infl_stream_t * __restrict st) {
+  if (!st)
+    return;
+  for (size_t i = 0; i < st->npages; i++)
+    free(st->pages[i]);
+  free(st->pages);
+  free(st->pieces);
+  free(st->gather);
+  free(st);
+}
+
+static piece_t *
+new_piece(infl_stream_t *st) {
+  if (st->npieces == st->cappieces) {
+    size_t   cap = st->cappieces ? st->cappieces * 2 : 16;
+    piece_t *np  = (piece_t *)realloc(st->pieces, cap * sizeof(*np));
+    if (!np)
+      return NULL;
+    st->pieces    = np;
+    st->cappieces = cap;
+  }
+  return &st->pieces[st->npieces++];
+}
+
+static uint8_t *
+next_page(infl_stream_t *st, int32_t *index) {
+  if (st->pages_used == st->npages) {
+    uint8_t *pg;
+    if (st->npages == st->cappages) {
+      size_t    cap = st->cappages ? st->cappages * 2 : 8;
+      uint8_t **np  = (uint8_t **)realloc(st->pages, cap * sizeof(*np));
+      if (!np)
+        return NULL;
+      st->pages    = np;
+      st->cappages = cap;
+    }
+    if (posix_memalign((void **)&pg, 64, PAGE_SIZE) != 0)
+      return NULL;
+    st->pages[st->npages++] = pg;
+  }
+  *index = (int32_t)st->pages_used;
+  return st->pages[st->pages_used++];
+}
+
+UNZ_EXPORT void
+infl_include(infl_stream_t * __restrict st, const void * __restrict ptr, uint32_t len) {
+  piece_t *pc;
+
+  if (!st)
+    return;
+
+  /* room left in the page being filled: append, whatever the size (mem.c:121-132) */
+  if (st->appending && len <= PAGE_SIZE - st->page_fill) {
+    pc = &st->pieces[st->npieces - 1];
+    if (len)
+      memcpy(st->pages[pc->page] + st->page_fill, ptr, len);
+    st->page_fill += len;
+    pc->len       += len;
+    st->srclen    += len;
+    return;
+  }
+
+  if (len <= APPEND_THRESHOLD) {                 /* small: copy into a fresh page */
+    int32_t  idx;
+    uint8_t *pg = next_page(st, &idx);
+    if (pg && (pc = new_piece(st))) {
+      if (len)
+        memcpy(pg, ptr, len);
+      pc->p         = pg;
+      pc->len       = len;
+      pc->page      = idx;
+      st->page_fill = len;
+      st->appending = 1;
+      st->srclen   += len;
+      return;
+    }
+    if (pg)
+      st->pages_used--;
+    /* out of memory: like the reference, fall through to borrowing */
+  }
+
+  pc = new_piece(st);                             /* large: borrow (mem.c:185-207) */
+  if (!pc)
+    return;                                       /* the reference drops it too (mem.c:191) */
+  pc->p         = (const uint8_t *)ptr;
+  pc->len       = len;
+  pc->page      = -1;
+  st->appending = 0;
+  st->srclen   += len;
+}
+
+/* Contiguous view of everything included so far; *out points either at the
+   single piece or at the stream's gather buffer. */
+static int
+gather_input(infl_stream_t *st, const uint8_t **out) {
+  size_t at = 0;
+
+  if (st->npieces == 1) {
+    *out = st->pieces[0].p;
+    return 0;
+  }
+  if (st->srclen > st->gather_cap) {
+    size_t   cap = st->srclen + st->srclen / 2 + 64;
+    uint8_t *nb  = (uint8_t *)realloc(st->gather, cap);
+    if (!nb)
+      return -1;
+    st->gather     = nb;
+    st->gather_cap = cap;
+  }
+  for (size_t i = 0; i < st->npieces; i++) {
+    if (st->pieces[i].len)
+      memcpy(st->gather + at, st->pieces[i].p, st->pieces[i].len);
+    at += st->pieces[i].len;
+  }
+  *out = st->gather;
+  return 0;
+}
+
+static int
+decode_one(infl_stream_t *st, int flags, int32_t *detail) {
+  const uint8_t *src;
+  uint64_t       soff[2], doff[2];
+  int32_t        status = UNZ_ERR;
+  uint32_t       outlen = 0, inpos = 0;
+  int            rc;
+
+  if (st->srclen > UINT32_MAX || gather_input(st, &src) != 0)
+    return UNZ_ERR;
+  soff[0] = 0; soff[1] = st->srclen;
+  doff[0] = 0; doff[1] = st->dstlen;
+  rc = infl_rt_batch_host(src, soff, st->dst, doff, NULL, flags, 1, &status, &outlen, detail,
+                          &inpos);
+  if (rc != 0) {
+    if (rc == -1)
+      warn_no_device();
+    return UNZ_ERR;
+  }
+  st->dstpos = outlen;
+  st->inpos  = inpos;
+  return status;
+}
+
+UNZ_EXPORT int
+infl(infl_stream_t * __restrict st) {
+  int32_t detail = 0;
+
+  if (!st)
+    return UNZ_ERR;
+  if (st->npieces == 0)
+    return UNZ_NOOP;                              /* nothing included: infl.c:1544-1545 */
+  return decode_one(st, st->flags == INFL_ZLIB ? INFL_ZLIB : 0, &detail);
+}
+
+UNZ_EXPORT int
+infl_stream(infl_stream_t * __restrict st, const void * __restrict src, uint32_t srclen) {
+  int32_t detail = INFL_D_OK;
+  int     rc;
+
+  if (!st)
+    return UNZ_ERR;
+  if (src && srclen > 0)
+    infl_include(st, src, srclen);
+  else if (st->npieces == 0)
+    return UNZ_OK;                                /* "empty data", stream.c:489-493 */
+  if (st->stream_done)
+    return UNZ_OK;
+
+  rc = decode_one(st, (st->flags == INFL_ZLIB ? INFL_ZLIB : 0) | INFL_F_PROGRESS, &detail);
+  if (rc == UNZ_OK) {
+    st->stream_done = 1;
+    return UNZ_OK;
+  }
+  switch (detail) {
+    case INFL_D_NEED_INPUT: return UNZ_UNFINISHED;
+    case INFL_D_FULL:       return UNZ_EFULL;
+    default:                return UNZ_ERR;
+  }
+}
+
+/* one launch over the streams of `streams` whose zlib-ness equals `zlib` */
+static int
+many_pass(infl_stream_t * const *streams, size_t n, int zlib, int32_t *status) {
+  uint64_t *soff, *doff;
+  uint32_t *outlen, *inpos;
+  int32_t  *st_tmp;
+  size_t   *idx;
+  void    **dptr;
+  uint8_t  *src = NULL;
+  size_t    m = 0, stotal = 0, dtotal = 0;
+  int       rc = 0;
+
+  for (size_t i = 0; i < n; i++)
+    if (streams[i] && streams[i]->npieces && (streams[i]->flags == INFL_ZLIB) == zlib)
+      m++;
+  if (m == 0)
+    return 0;
+
+  soff   = (uint64_t *)malloc((m + 1) * sizeof(*soff));
+  doff   = (uint64_t *)malloc((m + 1) * sizeof(*doff));
+  outlen = (uint32_t *)calloc(m, sizeof(*outlen));
+  inpos  = (uint32_t *)calloc(m, sizeof(*inpos));
+  st_tmp = (int32_t *)calloc(m, sizeof(*st_tmp));
+  idx    = (size_t *)malloc(m * sizeof(*idx));
+  dptr   = (void **)malloc(m * sizeof(*dptr));
+  if (!soff || !doff || !outlen || !inpos || !st_tmp || !idx || !dptr) {
+    rc = UNZ_ENOMEM;
+    goto out;
+  }
+  m = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (!(streams[i] && streams[i]->npieces && (streams[i]->flags == INFL_ZLIB) == zlib))
+      continue;
+    idx[m]  = i;
+    dptr[m] = streams[i]->dst;
+    soff[m] = stotal;
+    doff[m] = dtotal;
+    stotal += streams[i]->srclen;
+    dtotal += streams[i]->dstlen;
+    m++;
+  }
+  soff[m] = stotal;
+  doff[m] = dtotal;
+
+  src = (uint8_t *)calloc(1, stotal ? stotal : 1);
+  if (!src) {
+    rc = UNZ_ENOMEM;
+    goto out;
+  }
+  for (size_t k = 0; k < m; k++) {               /* chunk-list gather */
+    const infl_stream_t *st = streams[idx[k]];
+    size_t               at = soff[k];
+    for (size_t j = 0; j < st->npieces; j++) {
+      if (st->pieces[j].len)
+        memcpy(src + at, st->pieces[j].p, st->pieces[j].len);
+      at += st->pieces[j].len;
+    }
+  }
+
+  rc = infl_rt_batch_host(src, soff, NULL, doff, dptr, zlib ? INFL_ZLIB : 0, m, st_tmp, outlen,
+                          NULL, inpos);
+  if (rc == 0) {
+    for (size_t k = 0; k < m; k++) {
+      streams[idx[k]]->dstpos = outlen[k];
+      streams[idx[k]]->inpos  = inpos[k];
+      status[idx[k]]          = st_tmp[k];
+    }
+  } else {
+    if (rc == -1)
+      warn_no_device();
+    rc = rc == -12 ? UNZ_ENOMEM : UNZ_ERR;
+  }
+out:
+  free(soff); free(doff); free(outlen); free(inpos); free(st_tmp); free(idx); free(dptr);
+  free(src);
+  return rc;
+}
+
+UNZ_EXPORT int
+infl_many(infl_stream_t * const *streams, size_t n, int32_t *status) {
+  int rc;
+
+  if (n == 0)
+    return 0;
+  if (!streams || !status)
+    return UNZ_ERR;
+  for (size_t i = 0; i < n; i++)                 /* nothing included: infl.c:1544-1545 */
+    status[i] = (streams[i] && streams[i]->npieces) ? UNZ_ERR : UNZ_NOOP;
+  rc = many_pass(streams, n, 0, status);
+  if (rc == 0)
+    rc = many_pass(streams, n, 1, status);
+  return rc;
+}

@@ -1,0 +1,108 @@
+/*
+ * defl/infl_batch.h -- batched entry points of the MI355X inflate engine.
+ *
+ * The reference decodes one stream per call (infl(), src/infl/infl.c:1507-1675);
+ * one stream cannot occupy a GPU, so the engine adds calls that decode many
+ * independent streams with one kernel launch.  Each stream is decoded with the
+ * exact semantics of the reference's infl() on one contiguous input: the
+ * per-stream status is what infl() would return, outlen what infl_output_pos()
+ * would report afterwards, and dst[dst_off[i] .. dst_off[i] + outlen[i]) the
+ * bytes it would have produced.
+ *
+ * Plain C ABI: pointers and sizes only.  "dev" pointers are HIP device
+ * pointers (hipMalloc / a framework's device allocation); hip_stream is a
+ * hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef infl_batch_h
+#define infl_batch_h
+
+#include "common.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Selects the HIP device used by the calling thread for all later calls and
+   prepares the engine on it.  0, or UNZ_ERR if the device is unusable.  Replaces
+   nothing in the reference (it has no device notion). */
+UNZ_EXPORT int
+infl_gpu_init(int device);
+
+/* Number of usable HIP devices (0 if none / no driver). */
+UNZ_EXPORT int
+infl_gpu_device_count(void);
+
+/*
+ * Decodes n independent streams that are already resident in device memory.
+ *   dev_src      compressed arena
+ *   dev_src_off  n + 1 offsets into it; stream i is [off[i], off[i+1])
+ *   dev_dst      output arena
+ *   dev_dst_off  n + 1 offsets; stream i owns [off[i], off[i+1]) as capacity
+ *   flags        0 raw DEFLATE, INFL_ZLIB zlib wrapper (all streams alike)
+ *   dev_status   n result codes (UnzResult), as infl() returns them
+ *   dev_outlen   n output lengths, as infl_output_pos() reports them
+ * Asynchronous: the kernel is enqueued on hip_stream and the call returns.
+ * Returns 0 when enqueued, UNZ_ERR on a launch failure or bad argument.
+ * Per stream this replaces infl_buf() (reference include/defl/infl.h:125-145).
+ */
+UNZ_EXPORT int
+infl_batch_dev(const void *dev_src, const uint64_t *dev_src_off,
+               void *dev_dst, const uint64_t *dev_dst_off,
+               int flags, size_t n,
+               int32_t *dev_status, uint32_t *dev_outlen,
+               void *hip_stream);
+
+/*
+ * infl_batch_dev() plus one more output: dev_detail[i] says why stream i
+ * stopped (0 complete, 1 malformed, 2 input ended inside the stream, 3 output
+ * capacity reached, 4 internal safety stop).  The reference folds 1-3 into
+ * UNZ_ERR on this path (src/infl/infl.c:1074-1087); the extra array is for
+ * diagnosis and tests.
+ */
+UNZ_EXPORT int
+infl_batch_dev_detail(const void *dev_src, const uint64_t *dev_src_off,
+                      void *dev_dst, const uint64_t *dev_dst_off,
+                      int flags, size_t n,
+                      int32_t *dev_status, uint32_t *dev_outlen,
+                      int32_t *dev_detail, void *hip_stream);
+
+/*
+ * Same for host memory: uploads the arenas, decodes, downloads the results
+ * and returns when they are in place.  All pointers are host pointers.
+ * Returns 0, UNZ_ENOMEM or UNZ_ERR (no device).
+ */
+UNZ_EXPORT int
+infl_batch(const void *src, const uint64_t *src_off,
+           void *dst, const uint64_t *dst_off,
+           int flags, size_t n, int32_t *status, uint32_t *outlen);
+
+/*
+ * Deferred form of infl() for many streams that were filled with
+ * infl_include(): gathers every stream's chunk list into one staging arena,
+ * decodes all of them with one launch and stores each stream's result as
+ * infl() would have (status[i] is its return value; output position and bytes
+ * land in the stream's own destination).  Replaces a loop of infl() calls
+ * (reference src/infl/infl.c:1507-1675) over streams fed by infl_include()
+ * (src/infl/mem.c:114-216).
+ */
+UNZ_EXPORT int
+infl_many(infl_stream_t * const *streams, size_t n, int32_t *status);
+
+/* Device-memory helpers so that a plain C caller (or ctypes) can stage data
+   without linking HIP itself.  Thin wrappers over hipMalloc / hipFree /
+   hipMemcpy / hipDeviceSynchronize; 0 on success. */
+UNZ_EXPORT void *infl_gpu_malloc(size_t bytes);
+UNZ_EXPORT void  infl_gpu_free(void *dev_ptr);
+UNZ_EXPORT int   infl_gpu_upload(void *dev_dst, const void *host_src, size_t bytes);
+UNZ_EXPORT int   infl_gpu_download(void *host_dst, const void *dev_src, size_t bytes);
+UNZ_EXPORT int   infl_gpu_sync(void);
+
+/* Tuning knob for measurements: lanes of a wavefront that cooperate on one
+   stream (64, 32, 16 or 8).  Returns the value in effect. */
+UNZ_EXPORT int
+infl_gpu_set_lanes_per_stream(int lanes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* infl_batch_h */

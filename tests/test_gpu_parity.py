@@ -1,0 +1,286 @@
+"""GPU parity tests: the HIP engine, called through its C ABI, against the CPU oracle and the
+committed golden fixtures.  Integer/byte work: the bar is bit-exact (return code, output
+position, output bytes)."""
+import json
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import workloads as wl
+from defl_amd import capi
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "defl_testdata")
+ALL = sorted(os.listdir(os.path.join(DATA, "compressed")))
+PAIRS = [f for f in ALL if os.path.exists(os.path.join(DATA, "raw", f))]
+
+
+def _read(kind, name):
+    with open(os.path.join(DATA, kind, name), "rb") as f:
+        return f.read()
+
+
+def _check_batch(engine, oracle, streams, caps, flags, lanes=64, what=""):
+    """Runs one batch on the GPU (device-resident path) and on the oracle; compares everything."""
+    src, src_off, dst_off = wl.pack(streams, caps)
+    want_dst, want_status, want_outlen = oracle.infl_batch(src, src_off, dst_off, flags)
+    assert engine.lib.infl_gpu_set_lanes_per_stream(lanes) == lanes
+    b = engine.device_batch(src, src_off, dst_off)
+    try:
+        b.run(flags)
+        dst, status, outlen, detail = b.results()
+    finally:
+        b.free()
+        engine.lib.infl_gpu_set_lanes_per_stream(64)
+    bad = np.nonzero((status != want_status) | (outlen != want_outlen))[0]
+    assert bad.size == 0, (what, "stream", int(bad[0]), int(status[bad[0]]), int(want_status[bad[0]]),
+                           int(outlen[bad[0]]), int(want_outlen[bad[0]]), int(detail[bad[0]]))
+    for i in range(len(streams)):
+        a, n = int(dst_off[i]), int(outlen[i])
+        if not np.array_equal(dst[a:a + n], want_dst[a:a + n]):
+            k = int(np.nonzero(dst[a:a + n] != want_dst[a:a + n])[0][0])
+            raise AssertionError((what, "stream", i, "first bad byte", k, "of", n))
+    return status, outlen, detail
+
+
+def test_device_present(engine):
+    assert engine.lib.infl_gpu_device_count() >= 1
+    assert engine.lib.infl_gpu_init(0) == 0
+
+
+@pytest.mark.parametrize("name", PAIRS)
+def test_file_pair_infl_buf(engine, name):
+    """The reference's own file test (test_files.c:213-235) through the drop-in API."""
+    raw, comp = _read("raw", name), _read("compressed", name)
+    rc, pos, out = engine.infl_buf(comp, len(raw) + 1000, 0)
+    assert rc == capi.UNZ_OK
+    assert pos == len(raw) and out == raw
+
+
+@pytest.mark.parametrize("lanes", [64, 32, 16, 8])
+def test_all_fixtures_one_batch(engine, oracle, lanes):
+    streams = [_read("compressed", n) for n in ALL]
+    caps = [len(_read("raw", n)) + 1000 if n in PAIRS else 70000 for n in ALL]
+    status, outlen, _ = _check_batch(engine, oracle, streams, caps, 0, lanes, "fixtures")
+    for n, s, o in zip(ALL, status, outlen):
+        if n in PAIRS:
+            assert s == 0 and o == len(_read("raw", n)), n
+
+
+def test_kats(engine):
+    with open(os.path.join(HERE, "golden", "kats.json")) as f:
+        kats = json.load(f)["vectors"]
+    for k in kats:
+        rc, pos, out = engine.infl_buf(bytes.fromhex(k["src"]), k["dstlen"], k["flags"])
+        if k["expect"] == "err":
+            assert rc != capi.UNZ_OK, k["name"]
+        else:
+            assert rc == capi.UNZ_OK and out == bytes.fromhex(k["out"]), k["name"]
+
+
+def test_empty_input(engine):
+    assert engine.infl_buf(b"", 16, 0)[:2] == (capi.UNZ_OK, 0)
+    assert engine.infl_buf(b"", 16, 1)[:2] == (capi.UNZ_OK, 0)
+
+
+def _corpus(rng, n):
+    words = [bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(2, 10)))
+             for _ in range(300)]
+    out = bytearray()
+    while len(out) < n:
+        out += rng.choice(words) + rng.choice([b" ", b" ", b", ", b".\n"])
+    return bytes(out[:n])
+
+
+def _zlib_cases(seed):
+    rng = random.Random(seed)
+    for level in (0, 1, 6, 9):
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+            for size in (0, 1, 2, 100, 4097, 70000, 200000):
+                for kind in ("text", "random", "zeros", "mixed"):
+                    if kind == "text":
+                        raw = _corpus(rng, size)
+                    elif kind == "random":
+                        raw = rng.randbytes(size)
+                    elif kind == "zeros":
+                        raw = bytes(size)
+                    else:
+                        raw = _corpus(rng, size // 2) + rng.randbytes(size - size // 2)
+                    yield raw, level, strategy
+
+
+@pytest.mark.parametrize("lanes", [64, 32, 16, 8])
+@pytest.mark.parametrize("wrap", [0, 1])
+def test_zlib_streams_batch(engine, oracle, wrap, lanes):
+    """Valid streams of every block type; exact capacity, one byte short, generous."""
+    streams, caps, raws = [], [], []
+    for raw, level, strategy in _zlib_cases(7 + wrap):
+        comp = wl.deflate(raw, level, bool(wrap), strategy)
+        for cap in (len(raw), max(0, len(raw) - 1), len(raw) + 300):
+            streams.append(comp)
+            caps.append(cap)
+            raws.append(raw)
+    status, outlen, detail = _check_batch(engine, oracle, streams, caps, wrap, lanes, "zlib")
+    for i, raw in enumerate(raws):
+        if caps[i] >= len(raw):
+            assert status[i] == 0 and outlen[i] == len(raw)
+        else:
+            assert status[i] == -1 and detail[i] == capi.D_FULL
+
+
+@pytest.mark.parametrize("lanes", [64, 16])
+def test_fuzz_mutations_and_truncations(engine, oracle, lanes):
+    """Differential fuzz against the oracle on malformed input: flipped bits, truncation,
+    random bytes.  Return code, output position and bytes must match stream by stream."""
+    rng = random.Random(4242)
+    base = []
+    for i in range(12):
+        raw = _corpus(rng, rng.randint(50, 30000))
+        base.append(wl.deflate(raw, rng.choice([1, 6, 9]), False,
+                               rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE])))
+    base.append(wl.stored_stream(1, 5000, False)[1])
+    base.append(wl.stored_stream(2, 70000, False)[1] )
+    streams = []
+    for trial in range(6000):
+        b = bytearray(rng.choice(base))
+        mode = trial % 4
+        if mode == 0:
+            b = b[:rng.randint(0, len(b))]
+        elif mode == 1:
+            for _ in range(rng.randint(1, 4)):
+                if b:
+                    b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        elif mode == 2:
+            b = b[:rng.randint(1, min(len(b), 400))]
+            for _ in range(rng.randint(1, 3)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+        else:
+            b = bytearray(rng.randbytes(rng.randint(1, 300)))
+        streams.append(bytes(b))
+    caps = [rng.choice([0, 10, 1000, 40000, 80000]) for _ in streams]
+    for flags in (0, 1):
+        _check_batch(engine, oracle, streams, caps, flags, lanes, "fuzz flags=%d" % flags)
+
+
+def test_dynamic_header_edge_cases(engine, oracle):
+    """Hand-built dynamic headers: over-subscribed and incomplete code-length sets, repeat
+    codes at position 0 and past the end, symbols without an entry, table-capacity overflow."""
+    from tests.deflate_builder import header_cases
+    streams = header_cases()
+    caps = [4096] * len(streams)
+    _check_batch(engine, oracle, streams, caps, 0, 64, "headers")
+    _check_batch(engine, oracle, streams, caps, 0, 8, "headers")
+
+
+def test_text_batch_roundtrip_full_size(engine, oracle):
+    """Config-2 shaped batch (64 KiB text streams, zlib level 6): compare against the raw
+    text itself, and a sample against the oracle."""
+    n = 512
+    raws = [wl.text_stream(i) for i in range(n)]
+    streams = [wl.deflate(r) for r in raws]
+    src, src_off, dst_off = wl.pack(streams, [65536] * n)
+    b = engine.device_batch(src, src_off, dst_off)
+    try:
+        b.run(1)
+        dst, status, outlen, _ = b.results()
+    finally:
+        b.free()
+    assert (status == 0).all() and (outlen == 65536).all()
+    assert dst[:n * 65536].tobytes() == b"".join(raws)
+
+
+def test_host_batch_and_many(engine, oracle):
+    """infl_batch() on host memory and infl_many() over streams fed piecewise with
+    infl_include() (PNG-IDAT style) give the same bytes as the oracle on the joined input."""
+    import ctypes as C
+    n = 24
+    raws = [wl.png_like(i) for i in range(n)]
+    comps = [wl.deflate(r) for r in raws]
+    src, src_off, dst_off = wl.pack(comps, [len(r) for r in raws])
+    dst, status, outlen = engine.batch_host(src, src_off, dst_off, 1)
+    assert (status == 0).all()
+    assert dst[:int(dst_off[-1])].tobytes() == b"".join(raws)
+
+    lib = engine.lib
+    outs = [(C.c_uint8 * len(r))() for r in raws]
+    keep = []
+    sts = (C.c_void_p * n)()
+    for i in range(n):
+        sts[i] = lib.infl_init(outs[i], len(raws[i]), 1)
+        for piece in wl.idat_pieces(i, comps[i]):
+            buf = (C.c_uint8 * len(piece)).from_buffer_copy(piece)
+            keep.append(buf)
+            lib.infl_include(sts[i], buf, len(piece))
+    st_arr = (C.c_int32 * n)()
+    assert lib.infl_many(sts, n, st_arr) == 0
+    for i in range(n):
+        assert st_arr[i] == 0
+        assert lib.infl_output_pos(sts[i]) == len(raws[i])
+        assert bytes(outs[i]) == raws[i]
+        lib.infl_destroy(sts[i])
+
+
+def test_chunked_include_like_reference(engine):
+    """test_file_chunked of the reference (test_files.c:260-331): 1/2/4/8-byte pieces."""
+    for name in ("hello", "large_text_64k", "multiple_blocks", "png_simulation", "uncompressed_multi"):
+        import ctypes as C
+        raw, comp = _read("raw", name), _read("compressed", name)
+        out = (C.c_uint8 * (len(raw) + 1000))()
+        st = engine.lib.infl_init(out, len(raw) + 1000, 0)
+        pos, keep = 0, []
+        while pos < len(comp):
+            n = min(1 << (pos % 4), len(comp) - pos)
+            buf = (C.c_uint8 * n).from_buffer_copy(comp[pos:pos + n])
+            keep.append(buf)
+            engine.lib.infl_include(st, buf, n)
+            pos += n
+        assert engine.lib.infl(st) == capi.UNZ_OK
+        assert engine.lib.infl_output_pos(st) == len(raw)
+        assert bytes(out[:len(raw)]) == raw
+        engine.lib.infl_destroy(st)
+
+
+def test_streaming_api(engine):
+    """infl_stream() fed in 64..1024-byte pieces (test_files.c:688-790) and the zlib-header /
+    output-full cases: UNZ_UNFINISHED until complete, UNZ_EFULL resumable after a resize."""
+    import ctypes as C
+    lib = engine.lib
+    for name, step in (("hello", 64), ("multiple_blocks", 128), ("large_text_64k", 256), ("log_pattern", 512)):
+        raw, comp = _read("raw", name), _read("compressed", name)
+        out = (C.c_uint8 * (len(raw) + 16))()
+        st = lib.infl_init(out, len(raw) + 16, 0)
+        rc = capi.UNZ_UNFINISHED
+        keep = []
+        for pos in range(0, len(comp), step):
+            piece = comp[pos:pos + step]
+            buf = (C.c_uint8 * len(piece)).from_buffer_copy(piece)
+            keep.append(buf)
+            rc = lib.infl_stream(st, buf, len(piece))
+            assert rc in (capi.UNZ_OK, capi.UNZ_UNFINISHED)
+            if pos + step < len(comp) and rc == capi.UNZ_UNFINISHED:
+                assert lib.infl_output_pos(st) <= len(raw)
+        assert rc == capi.UNZ_OK
+        assert bytes(out[:len(raw)]) == raw and lib.infl_output_pos(st) == len(raw)
+        lib.infl_destroy(st)
+
+    raw = wl.text_stream(5, 20000)
+    comp = wl.deflate(raw)
+    small = (C.c_uint8 * 5000)()
+    st = lib.infl_init(small, 5000, 1)
+    src = (C.c_uint8 * len(comp)).from_buffer_copy(comp)
+    assert lib.infl_stream(st, src, 1) == capi.UNZ_UNFINISHED      # waits for the 2-byte header
+    assert lib.infl_stream(st, C.byref(src, 1), len(comp) - 1) == capi.UNZ_EFULL
+    got = lib.infl_output_pos(st)
+    assert 0 < got <= 5000 and bytes(small[:got]) == raw[:got]
+    big = (C.c_uint8 * 20000)()
+    C.memmove(big, small, got)
+    assert lib.infl_resize_output(st, big, 20000) == capi.UNZ_OK
+    assert lib.infl_stream(st, None, 0) == capi.UNZ_OK
+    assert bytes(big) == raw
+    lib.infl_destroy(st)
