@@ -195,7 +195,7 @@ __device__ __noinline__ bool build_table(uint32_t *table, const uint8_t *lens, u
 
   group_sync();
   for (uint32_t i = lig; i < cap; i += T) table[i] = 0;
-  if (lig < 16) L.count[lig] = 0;
+  for (int i = lig; i < 16; i += T) L.count[i] = 0;
   if (lig == 0) L.used = main_size;
   group_sync();
 
@@ -329,7 +329,7 @@ __device__ __noinline__ bool setup_fixed(StreamLds &L, int lig, int gshift) {
 // Dynamic block header (rules of infl.c:903-1000, including "at least 7 bits
 // must be left before every code-length symbol", :947).
 template <int T>
-__device__ __noinline__ int setup_dynamic(Reader &r, StreamLds &L, int lig, int gshift) {
+__device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds &L, int lig, int gshift) {
   rd_fill(r);
   if (r.n < 14) return INFL_D_NEED_INPUT;
   uint32_t hlit  = ((uint32_t)r.bits & 31u) + 257u;
@@ -401,7 +401,7 @@ __device__ __noinline__ int setup_dynamic(Reader &r, StreamLds &L, int lig, int 
 
 // Stored block reached through the block loop (rules of infl.c:659-715).
 template <int T>
-__device__ __noinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap, int lig) {
+__device__ __forceinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap, int lig) {
   rd_drop(r, r.n & 7u);
   rd_fill(r);
   if (r.n < 32) return INFL_D_NEED_INPUT;
@@ -420,7 +420,7 @@ __device__ __noinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &pos,
 
 // One Huffman-coded block (rules of infl.c:717-901).
 template <int T>
-__device__ __noinline__ int huffman_block(Reader &r, uint8_t *dst, uint32_t &pos_io, uint32_t cap,
+__device__ __forceinline__ int huffman_block(Reader &r, uint8_t *dst, uint32_t &pos_io, uint32_t cap,
                              const StreamLds &L, int lig, uint64_t &fuel) {
   uint32_t pos = pos_io;
   for (;;) {

@@ -1,0 +1,99 @@
+// Host-side emulation harness: compiles defl_amd/csrc/infl_kernels.hip with g++ (through the
+// stand-in hip/hip_runtime.h next to this file) and runs each workgroup as 64 host threads.
+// Lanes of a group meet at a real barrier wherever the kernel has a wavefront fence, a
+// wave_barrier or a ballot, which is where the hardware's lockstep makes their memory
+// operations ordered.  Test infrastructure only.
+#include <pthread.h>
+
+#include <thread>
+#include <vector>
+
+#include "hip/hip_runtime.h"
+
+namespace emu {
+struct Group {
+  pthread_barrier_t     bar;
+  std::atomic<uint64_t> mask{0};
+};
+thread_local dim3   t_threadIdx, t_blockIdx;
+thread_local Group *t_group = nullptr;
+thread_local int    t_lane  = 0;
+int                 g_lanes_per_group = 64;
+
+void group_barrier() { pthread_barrier_wait(&t_group->bar); }
+
+uint64_t ballot(bool pred) {
+  if (pred) t_group->mask.fetch_or(1ull << t_lane);
+  group_barrier();
+  uint64_t m = t_group->mask.load();
+  group_barrier();
+  if (t_lane % g_lanes_per_group == 0) t_group->mask.store(0);
+  group_barrier();
+  return m;
+}
+
+void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
+  const int T = g_lanes_per_group, ngroups = (int)block / T;
+  for (unsigned b = 0; b < grid; b++) {
+    std::vector<Group> groups(ngroups);
+    for (auto &g : groups) pthread_barrier_init(&g.bar, nullptr, T);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < block; t++)
+      th.emplace_back([&, t] {
+        t_threadIdx = dim3(t);
+        t_blockIdx  = dim3(b);
+        t_lane      = (int)t;
+        t_group     = &groups[t / T];
+        fn();
+      });
+    for (auto &x : th) x.join();
+    for (auto &g : groups) pthread_barrier_destroy(&g.bar);
+  }
+}
+}  // namespace emu
+
+#include "../../defl_amd/csrc/infl_kernels.hip"
+
+extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
+                              int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
+                              uint32_t *inpos, int lanes) {
+  emu::g_lanes_per_group = lanes;
+  return infl_launch_batch(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, nullptr);
+}
+
+// emu_run <in.bin> <out.bin> <lanes> <flags>
+//   in : u64 n, u64 src_off[n+1], u64 dst_off[n+1], src bytes
+//   out: i32 status[n], u32 outlen[n], i32 detail[n], u32 inpos[n], dst bytes
+// The arenas are allocated with their exact sizes so that AddressSanitizer sees any access
+// past a stream's input or output capacity at the arena ends.
+#include <stdio.h>
+#include <stdlib.h>
+
+int main(int argc, char **argv) {
+  if (argc < 5) return 2;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, f) != 1) return 2;
+  std::vector<uint64_t> so(n + 1), dof(n + 1);
+  if (fread(so.data(), 8, n + 1, f) != n + 1 || fread(dof.data(), 8, n + 1, f) != n + 1) return 2;
+  uint8_t *src = (uint8_t *)malloc(so[n] ? so[n] : 1);
+  uint8_t *dst = (uint8_t *)calloc(1, dof[n] ? dof[n] : 1);
+  if (so[n] && fread(src, 1, so[n], f) != so[n]) return 2;
+  fclose(f);
+  std::vector<int32_t>  status(n, -99), detail(n, -99);
+  std::vector<uint32_t> outlen(n, 0), inpos(n, 0);
+  int rc = emu_infl_batch(src, so.data(), dst, dof.data(), atoi(argv[4]), n, status.data(), outlen.data(),
+                          detail.data(), inpos.data(), atoi(argv[3]));
+  if (rc != 0) return 3;
+  f = fopen(argv[2], "wb");
+  fwrite(status.data(), 4, n, f);
+  fwrite(outlen.data(), 4, n, f);
+  fwrite(detail.data(), 4, n, f);
+  fwrite(inpos.data(), 4, n, f);
+  fwrite(dst, 1, dof[n], f);
+  fclose(f);
+  free(src);
+  free(dst);
+  return 0;
+}

@@ -1,0 +1,62 @@
+// Stand-in for <hip/hip_runtime.h> used ONLY by the host-side kernel emulation in tests/emu:
+// it lets g++ compile the kernel source unchanged and run every "lane" as a host thread, so
+// that the kernel's own logic (indexing, bounds, lockstep hand-offs) can be checked on the CPU
+// under AddressSanitizer before a GPU ever runs it.  Test infrastructure, never shipped.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <atomic>
+#include <functional>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint4 { uint32_t x, y, z, w; };
+typedef void *hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+
+#define __device__
+#define __global__
+#define __shared__ static
+#define __forceinline__ inline
+#define __noinline__
+#define __launch_bounds__(...)
+
+namespace emu {
+struct Group;
+extern thread_local dim3   t_threadIdx, t_blockIdx;
+extern thread_local Group *t_group;
+extern thread_local int    t_lane;
+void     group_barrier();
+uint64_t ballot(bool pred);
+void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
+}  // namespace emu
+
+#define threadIdx emu::t_threadIdx
+#define blockIdx emu::t_blockIdx
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+  emu::launch((grid).x, (block).x, [=] { kern(__VA_ARGS__); })
+
+#define __builtin_amdgcn_fence(order, scope) emu::group_barrier()
+#define __builtin_amdgcn_wave_barrier() emu::group_barrier()
+#define __ballot(p) emu::ballot(p)
+#define __popcll(x) __builtin_popcountll(x)
+
+static inline uint32_t __brev(uint32_t v) {
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+  return __builtin_bswap32(v);
+}
+static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicMax(uint32_t *p, uint32_t v) {
+  uint32_t old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+  }
+  return old;
+}

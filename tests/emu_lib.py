@@ -1,0 +1,38 @@
+"""Runs the kernel source on the CPU through tests/emu (one host thread per lane, ASan on)."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+EXE = os.path.join(EMU_DIR, "emu_run")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+
+
+def run(src, src_off, dst_off, flags=0, lanes=64, timeout=600):
+    build()
+    n = len(src_off) - 1
+    src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
+    dst_off = np.ascontiguousarray(dst_off, dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint8)[: int(src_off[-1])]
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.uint64(n).tobytes() + src_off.tobytes() + dst_off.tobytes() + src.tobytes())
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+        p = subprocess.run([EXE, fin, fout, str(lanes), str(flags)], env=env, timeout=timeout,
+                           capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("emu_run failed (%d): %s" % (p.returncode, p.stderr[-3000:]))
+        raw = open(fout, "rb").read()
+    status = np.frombuffer(raw, dtype=np.int32, count=n, offset=0)
+    outlen = np.frombuffer(raw, dtype=np.uint32, count=n, offset=4 * n)
+    detail = np.frombuffer(raw, dtype=np.int32, count=n, offset=8 * n)
+    inpos = np.frombuffer(raw, dtype=np.uint32, count=n, offset=12 * n)
+    dst = np.frombuffer(raw, dtype=np.uint8, offset=16 * n)
+    return dst, status, outlen, detail, inpos

@@ -1,0 +1,68 @@
+"""Multi-process (world_size 2, gloo, CPU) coverage of the N>1 path: stream partitioning and
+the result-counter reduction.  The decode itself needs a GPU; here each rank 'decodes' its
+shard with the CPU oracle, which is what the reduction is agnostic to."""
+import os
+import socket
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import workloads as wl
+from defl_amd import shard
+
+
+def test_partition_balances_and_covers():
+    rng = np.random.default_rng(1)
+    cost = rng.integers(1000, 300000, size=5000)
+    for world in (1, 2, 3, 8):
+        parts = shard.partition(cost, world)
+        assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == len(cost)
+        for (a, b), (c, d) in zip(parts, parts[1:]):
+            assert b == c and a <= b
+        loads = [cost[a:b].sum() for a, b in parts]
+        assert max(loads) <= 1.05 * cost.sum() / world + cost.max()
+    assert shard.partition([], 4) == [(0, 0)] * 4
+    assert shard.partition([5], 2) in ([(0, 0), (0, 1)], [(0, 1), (1, 1)])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import oracle_lib
+    oracle = oracle_lib.load()
+    raws = [wl.text_stream(i, 3000 + 37 * i) for i in range(n)]
+    comps = [wl.deflate(r) for r in raws]
+    comps[3] = comps[3][:40]                       # one broken stream
+    cost = [len(c) + len(r) for c, r in zip(comps, raws)]
+    lo, hi = shard.partition(cost, world)[rank]
+    src, so, do = wl.pack(comps[lo:hi], [len(r) for r in raws[lo:hi]])
+    _, status, outlen = oracle.infl_batch(src, so, do, 1, 1)
+    q.put((rank, shard.summarize(status, outlen, dist)))
+    dist.destroy_process_group()
+
+
+def test_world2_shard_and_reduce():
+    n, world = 40, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    raws_total = sum(3000 + 37 * i for i in range(n)) - (3000 + 37 * 3)
+    for _, (n_ok, n_err, nbytes) in got:
+        assert (n_ok, n_err, nbytes) == (n - 1, 1, raws_total)
