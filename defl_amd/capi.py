@@ -22,7 +22,7 @@ EXPORTS = [
     "infl_destroy", "infl_stream", "infl_output_pos", "infl_input_pos",
     "infl_gpu_init", "infl_gpu_device_count", "infl_batch_dev", "infl_batch_dev_detail", "infl_batch",
     "infl_many", "infl_gpu_malloc", "infl_gpu_free", "infl_gpu_upload", "infl_gpu_download",
-    "infl_gpu_sync", "infl_gpu_set_lanes_per_stream",
+    "infl_gpu_sync", "infl_gpu_set_lanes_per_stream", "infl_gpu_set_table_variant",
 ]
 
 
@@ -127,6 +127,7 @@ class Engine:
             "infl_gpu_download": (i32, [vp, vp, sz]),
             "infl_gpu_sync": (i32, []),
             "infl_gpu_set_lanes_per_stream": (i32, [i32]),
+            "infl_gpu_set_table_variant": (i32, [i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)

@@ -22,6 +22,10 @@ extern "C" {
 #define INFL_D_FULL        3   /* output capacity reached                   */
 #define INFL_D_INTERNAL    4   /* safety counter ran out (engine bug)       */
 
+/* status value the first (compact-table) pass leaves for a stream that the
+   second pass has to decode; never visible to callers */
+#define INFL_STATUS_DEFERRED 0x40000000
+
 /* kernel flag bits: bit 0 = zlib wrapper; INFL_F_PROGRESS = when a stream stops
    for lack of input or output space, report the output position it reached in
    `outlen` (the one-shot API must report 0 there, like the reference) */
@@ -30,11 +34,14 @@ extern "C" {
 
 /* Enqueues the batch kernel; all pointers are device pointers; `detail` (why a
    stream stopped) and `inpos` (input bytes consumed) may be NULL.  lanes =
-   lanes of a wavefront per stream (64/32/16/8).  0 or -1. */
+   lanes of a wavefront per stream (64/32/16/8).  variant 0 = one launch with
+   tables in the reference's geometry; variant 1 = a first launch with compact
+   16-bit tables (more streams in flight) plus a second launch in the
+   reference's geometry for the streams the first one deferred.  0 or -1. */
 int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                       const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                       uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
-                      void *stream);
+                      int variant, void *stream);
 
 /* Host-memory batch; used by infl(), infl_many() and infl_stream().  Stream i
    reads src[src_off[i] .. src_off[i+1]) and has dst_off[i+1] - dst_off[i] bytes

@@ -18,6 +18,7 @@ namespace {
 
 std::mutex g_mu;            // guards the cached workspace below
 int        g_lanes = 64;    // lanes of a wavefront per stream
+int        g_variant = 0;   // 0 reference-geometry tables, 1 compact tables + deferred pass
 
 struct Buf {
   void  *p   = nullptr;
@@ -128,13 +129,18 @@ int infl_gpu_set_lanes_per_stream(int lanes) {
   return g_lanes;
 }
 
+int infl_gpu_set_table_variant(int variant) {
+  if (variant == 0 || variant == 1) g_variant = variant;
+  return g_variant;
+}
+
 int infl_batch_dev(const void *dev_src, const uint64_t *dev_src_off, void *dev_dst,
                    const uint64_t *dev_dst_off, int flags, size_t n, int32_t *dev_status,
                    uint32_t *dev_outlen, void *hip_stream) {
   if (n == 0) return 0;
   if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen) return -1;
   return infl_launch_batch(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status,
-                           dev_outlen, nullptr, nullptr, g_lanes, hip_stream);
+                           dev_outlen, nullptr, nullptr, g_lanes, g_variant, hip_stream);
 }
 
 // Same with the per-stream detail codes (INFL_D_*); for tests and diagnosis.
@@ -144,7 +150,7 @@ int infl_batch_dev_detail(const void *dev_src, const uint64_t *dev_src_off, void
   if (n == 0) return 0;
   if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen) return -1;
   return infl_launch_batch(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status,
-                           dev_outlen, dev_detail, nullptr, g_lanes, hip_stream);
+                           dev_outlen, dev_detail, nullptr, g_lanes, g_variant, hip_stream);
 }
 
 int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
@@ -175,7 +181,7 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
   if (!ok) return -1;
   if (infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p,
                         flags, n, (int32_t *)w.status.p, (uint32_t *)w.outlen.p,
-                        (int32_t *)w.detail.p, (uint32_t *)w.inpos.p, g_lanes, st) != 0)
+                        (int32_t *)w.detail.p, (uint32_t *)w.inpos.p, g_lanes, g_variant, st) != 0)
     return -1;
   ok &= hipMemcpyAsync(status, w.status.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
   ok &= hipMemcpyAsync(outlen, w.outlen.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;

@@ -4,15 +4,26 @@
 // independent stream with the semantics of recp/defl's one-shot infl() on a
 // single contiguous input (reference src/infl/infl.c:1507-1551 dispatcher,
 // :94-267 stored-only path, :1002-1104 block loop, :903-1000 dynamic header,
-// :452-578 table build, :717-901 symbol loop).  Nothing here is translated from
-// that file: the reference is a scalar CPU loop over a 64-bit reservoir, this is
-// a SIMT kernel whose lanes share the decode tables in LDS, replicate the bit
-// reservoir in registers, build the tables cooperatively and copy LZ77 matches
-// and stored blocks with one byte (or 16 bytes) per lane.
+// :452-578 table build and its acceptance rules, :717-901 symbol loop).
+// Nothing here is translated from that file: the reference is a scalar CPU loop
+// over a 64-bit reservoir; this is a SIMT kernel whose lanes share the decode
+// tables of their stream in LDS, replicate the bit reservoir in registers, lay
+// the tables out analytically from the code-length histogram, build them
+// cooperatively and copy LZ77 matches and stored blocks one byte (or 16 bytes)
+// per lane.
 //
-// All arithmetic is integer; the only floating point instruction class that
-// hipcc could pack is therefore absent, but the file is still compiled with
-// packed-fp32 ops disabled (see the build script).
+// Two table formats exist:
+//   RefFmt      32-bit entries in the reference's own geometry (10-bit literal
+//               and 8-bit distance main tables, 2048 / 512 entries).  Decodes
+//               every stream and produces the reference's exact failure result.
+//   CompactFmt  16-bit entries, 9-bit / 7-bit main tables, 768 / 320 entries:
+//               a quarter of the LDS per stream, so four times as many streams
+//               are in flight per CU.  A stream whose tables do not fit, or
+//               that fails in any way, is handed over ("deferred") to a second
+//               launch that uses RefFmt, so results never depend on the format.
+//
+// All arithmetic is integer.  The file is compiled with packed-fp32 ops off
+// like every HIP source of this library (see the Makefile).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -20,57 +31,142 @@
 
 namespace defl {
 
-// ---------------------------------------------------------------------------
-// Decode-table entry, same packing as the reference's fast tables
-// (infl.c:385-397): bits 0-4 total = codelen + xbits, 5-8 codelen, 9-12 xbits,
-// 13 LITERAL, 14 END, 15 SUBTABLE, 16-31 base value or subtable offset.
-// ---------------------------------------------------------------------------
-constexpr uint32_t E_LITERAL = 1u << 13;
-constexpr uint32_t E_END     = 1u << 14;
-constexpr uint32_t E_SUB     = 1u << 15;
+constexpr int REF_LIT_BITS  = 10;     // infl.c:378
+constexpr int REF_DIST_BITS = 8;      // infl.c:379
+constexpr int REF_LIT_CAP   = 2048;   // infl.c:382
+constexpr int REF_DIST_CAP  = 512;    // infl.c:383
 
-constexpr int LIT_BITS  = 10;     // infl.c:378
-constexpr int DIST_BITS = 8;      // infl.c:379
-constexpr int LIT_CAP   = 2048;   // infl.c:382
-constexpr int DIST_CAP  = 512;    // infl.c:383
-
-__device__ __forceinline__ uint32_t mk_entry(uint32_t base, uint32_t xbits, uint32_t codelen,
-                                             uint32_t flags) {
-  return (base << 16) | flags | (xbits << 9) | (codelen << 5) | (codelen + xbits);
-}
+// A decoded table entry, format independent.
+enum : uint32_t { K_INVALID = 0, K_LITERAL = 1, K_END = 2, K_BASE = 3 };
+struct Sym {
+  uint32_t kind;      // K_*
+  uint32_t codelen;   // Huffman code length
+  uint32_t xbits;     // extra bits that follow the code
+  uint32_t base;      // literal byte, length base or distance base
+};
 
 // RFC 1951 length / distance bases computed instead of looked up
-// (values of apicommon.h:36-49).
-__device__ __forceinline__ uint32_t litlen_entry(uint32_t sym, uint32_t len) {
-  if (sym < 256) return mk_entry(sym, 0, len, E_LITERAL);
-  if (sym == 256) return mk_entry(0, 0, len, E_END);
-  if (sym > 285) return 0;                         // 286, 287 never get an entry
-  uint32_t i = sym - 257;
-  if (i < 8) return mk_entry(3 + i, 0, len, 0);
-  if (i == 28) return mk_entry(258, 0, len, 0);
-  uint32_t xb = (i - 4) >> 2;
-  return mk_entry(3 + ((4 + (i & 3)) << xb), xb, len, 0);
+// (values of apicommon.h:36-49).  `i` = length symbol - 257.
+__device__ __forceinline__ void length_base(uint32_t i, uint32_t &base, uint32_t &xb) {
+  xb   = i < 8 || i == 28 ? 0u : (i - 4) >> 2;
+  base = i < 8 ? 3 + i : i == 28 ? 258u : 3 + ((4 + (i & 3)) << xb);
+}
+__device__ __forceinline__ void dist_base(uint32_t d, uint32_t &base, uint32_t &xb) {
+  xb   = d < 4 ? 0u : (d >> 1) - 1;
+  base = d < 4 ? 1 + d : 1 + ((2 + (d & 1)) << xb);
 }
 
-__device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t len) {
-  if (sym > 29) return 0;                          // 30, 31 never get an entry
-  if (sym < 4) return mk_entry(1 + sym, 0, len, 0);
-  uint32_t xb = (sym >> 1) - 1;
-  return mk_entry(1 + ((2 + (sym & 1)) << xb), xb, len, 0);
-}
+// ---------------------------------------------------------------------------
+// RefFmt: the reference's packed 32-bit entry (infl.c:385-397): bits 0-4
+// codelen + xbits, 5-8 codelen, 9-12 xbits, 13 LITERAL, 14 END, 15 SUBTABLE,
+// 16-31 base value or subtable offset.
+// ---------------------------------------------------------------------------
+struct RefFmt {
+  typedef uint32_t entry_t;
+  static constexpr int LIT_BITS = REF_LIT_BITS, DIST_BITS = REF_DIST_BITS;
+  static constexpr int LIT_CAP = REF_LIT_CAP, DIST_CAP = REF_DIST_CAP;
+  static constexpr uint32_t F_LITERAL = 1u << 13, F_END = 1u << 14, F_SUB = 1u << 15;
+
+  static __device__ __forceinline__ uint32_t pack(uint32_t base, uint32_t xb, uint32_t len, uint32_t f) {
+    return (base << 16) | f | (xb << 9) | (len << 5) | (len + xb);
+  }
+  static __device__ __forceinline__ entry_t lit_entry(uint32_t sym, uint32_t len) {
+    if (sym < 256) return pack(sym, 0, len, F_LITERAL);
+    if (sym == 256) return pack(0, 0, len, F_END);
+    if (sym > 285) return 0;                     // 286, 287 never get an entry (infl.c:433-438)
+    uint32_t base, xb;
+    length_base(sym - 257, base, xb);
+    return pack(base, xb, len, 0);
+  }
+  static __device__ __forceinline__ entry_t dist_entry(uint32_t sym, uint32_t len) {
+    if (sym > 29) return 0;                      // 30, 31 never get an entry (infl.c:445-446)
+    uint32_t base, xb;
+    dist_base(sym, base, xb);
+    return pack(base, xb, len, 0);
+  }
+  static __device__ __forceinline__ entry_t sub_entry(uint32_t at, uint32_t bits) {
+    return (at << 16) | F_SUB | (bits << 5);
+  }
+  static __device__ __forceinline__ bool is_sub(uint32_t e) { return e & F_SUB; }
+  static __device__ __forceinline__ uint32_t sub_at(uint32_t e) { return e >> 16; }
+  static __device__ __forceinline__ uint32_t sub_bits(uint32_t e) { return (e >> 5) & 15u; }
+  static __device__ __forceinline__ Sym lit_sym(uint32_t e) {
+    Sym s;
+    s.kind    = !e ? K_INVALID : (e & F_LITERAL) ? K_LITERAL : (e & F_END) ? K_END : K_BASE;
+    s.codelen = (e >> 5) & 15u;
+    s.xbits   = (e >> 9) & 15u;
+    s.base    = e >> 16;
+    return s;
+  }
+  static __device__ __forceinline__ Sym dist_sym(uint32_t e) { return lit_sym(e); }
+};
+
+// ---------------------------------------------------------------------------
+// CompactFmt: 16-bit entries.  bits 0-3 code length (or subtable index bits),
+// bits 4-12 payload, bit 13 SUBTABLE, bit 14 BASE (length / distance symbol),
+// bit 15 LITERAL; END carries only its flag and a length, 0 = no code.
+// Length and distance bases are recomputed from the symbol index at decode.
+// ---------------------------------------------------------------------------
+struct CompactFmt {
+  typedef uint16_t entry_t;
+  static constexpr int LIT_BITS = 9, DIST_BITS = 7;
+  static constexpr int LIT_CAP = 768, DIST_CAP = 320;
+  static constexpr uint32_t F_LITERAL = 1u << 15, F_BASE = 1u << 14, F_SUB = 1u << 13, F_END = 1u << 12;
+
+  static __device__ __forceinline__ entry_t lit_entry(uint32_t sym, uint32_t len) {
+    if (sym < 256) return (entry_t)(F_LITERAL | (sym << 4) | len);
+    if (sym == 256) return (entry_t)(F_END | len);
+    if (sym > 285) return 0;
+    return (entry_t)(F_BASE | ((sym - 257) << 4) | len);
+  }
+  static __device__ __forceinline__ entry_t dist_entry(uint32_t sym, uint32_t len) {
+    if (sym > 29) return 0;
+    return (entry_t)(F_BASE | (sym << 4) | len);
+  }
+  // subtable offsets are even (main table and every subtable have even sizes): at / 2 fits 9 bits
+  static __device__ __forceinline__ entry_t sub_entry(uint32_t at, uint32_t bits) {
+    return (entry_t)(F_SUB | ((at >> 1) << 4) | bits);
+  }
+  static __device__ __forceinline__ bool is_sub(uint32_t e) { return e & F_SUB; }
+  static __device__ __forceinline__ uint32_t sub_at(uint32_t e) { return ((e >> 4) & 0x1ffu) << 1; }
+  static __device__ __forceinline__ uint32_t sub_bits(uint32_t e) { return e & 15u; }
+  static __device__ __forceinline__ Sym lit_sym(uint32_t e) {
+    Sym s;
+    s.codelen = e & 15u;
+    s.xbits   = 0;
+    s.base    = (e >> 4) & 0xffu;
+    if (e & F_LITERAL) {
+      s.kind = K_LITERAL;
+    } else if (e & F_BASE) {
+      s.kind = K_BASE;
+      length_base(s.base & 31u, s.base, s.xbits);
+    } else {
+      s.kind = e ? K_END : K_INVALID;
+    }
+    return s;
+  }
+  static __device__ __forceinline__ Sym dist_sym(uint32_t e) {
+    Sym s;
+    s.codelen = e & 15u;
+    s.kind    = e ? K_BASE : K_INVALID;
+    dist_base((e >> 4) & 31u, s.base, s.xbits);
+    return s;
+  }
+};
 
 // Per-stream working set in LDS.
+template <class F>
 struct StreamLds {
-  uint32_t lit[LIT_CAP];      // 8 KiB
-  uint32_t dist[DIST_CAP];    // 2 KiB
-  uint16_t rev[320];          // bit-reversed canonical code per symbol; the
-                              // code-length alphabet's 256-entry table lives
-                              // here while the header is being read
-  uint8_t  lens[320];         // code lengths of the block being set up
-  uint32_t count[16];
-  uint32_t next[16];
-  uint32_t used;
+  typename F::entry_t lit[F::LIT_CAP];
+  typename F::entry_t dist[F::DIST_CAP];   // also holds the 256-entry (16-bit) table of the
+                                           // code-length alphabet while a header is read
+  uint8_t  lens[320];                      // code lengths of the block being set up
+  uint32_t count[16];                      // symbols per code length
+  uint32_t next[16];                       // next canonical code per length
+  uint16_t cls_lo[16], cls_hi[16], cls_at[16];   // subtable classes per code length
 };
+static_assert(sizeof(CompactFmt::entry_t) * CompactFmt::DIST_CAP >= 512, "code-length table must fit");
+static_assert(CompactFmt::LIT_CAP / 2 <= 512 && CompactFmt::DIST_CAP / 2 <= 512, "9-bit subtable offsets");
 
 // Lanes of a group run in lockstep inside one wavefront; LDS and global
 // operations of a wavefront are issued in program order, so the only thing a
@@ -88,7 +184,7 @@ __device__ __forceinline__ void group_sync() {
 // 32-bit word so that the global load latency overlaps with symbol decode.
 // ---------------------------------------------------------------------------
 struct Reader {
-  const uint8_t *p;      // next byte not yet handed to `nextw`'s successor
+  const uint8_t *p;      // first input byte not yet moved into `bits`
   const uint8_t *end;
   uint64_t       bits;
   uint32_t       n;
@@ -133,15 +229,14 @@ __device__ __forceinline__ void rd_drop(Reader &r, uint32_t k) {
   r.n    -= k;
 }
 
-// byte offset (from `base`) of the first byte that still has unread bits
-__device__ __forceinline__ const uint8_t *rd_byte_ptr(const Reader &r) {
-  return r.p - (r.n >> 3);
-}
+// first input byte that still has unread bits
+__device__ __forceinline__ const uint8_t *rd_byte_ptr(const Reader &r) { return r.p - (r.n >> 3); }
 
-__device__ __forceinline__ uint32_t tab_lookup(const uint32_t *tab, int mainbits, uint32_t bits) {
+template <class F>
+__device__ __forceinline__ uint32_t tab_lookup(const typename F::entry_t *tab, int mainbits,
+                                               uint32_t bits) {
   uint32_t e = tab[bits & ((1u << mainbits) - 1u)];
-  if (e & E_SUB)
-    e = tab[(e >> 16) + ((bits >> mainbits) & ((1u << ((e >> 5) & 15u)) - 1u))];
+  if (F::is_sub(e)) e = tab[F::sub_at(e) + ((bits >> mainbits) & ((1u << F::sub_bits(e)) - 1u))];
   return e;
 }
 
@@ -181,45 +276,110 @@ __device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t pos, uint32_t 
 }
 
 // ---------------------------------------------------------------------------
-// Two-level table build for one alphabet (acceptance rules of infl.c:452-578:
-// a length set is rejected when over-subscribed or when main table plus
-// subtables exceed `cap`; incomplete sets are accepted; symbols without an
-// entry still take part in code assignment and subtable sizing).
-// `lens` is in LDS and complete; returns false on rejection (group-uniform).
+// Table build for one alphabet.
+//
+// Acceptance is the reference's (infl.c:452-578): reject an over-subscribed
+// length set, reject when the main table plus all subtables of the REFERENCE
+// geometry (ref_bits / ref_cap) exceed its capacity, accept incomplete sets;
+// symbols without an entry still take part in code assignment and subtable
+// sizing.  Returns BUILD_OK, BUILD_REJECT (the reference rejects this set) or
+// BUILD_NOFIT (valid, but larger than this format's own capacity).
+//
+// Layout.  Canonical codes of one length are consecutive, so the main-table
+// prefixes that need a subtable, and the widest code under each of them, follow
+// from the histogram alone: for length l > mainbits the codes cover the prefix
+// range [first[l] >> (l - mainbits), (first[l] + count[l] - 1) >> (l - mainbits)];
+// ranges of growing l are ordered and overlap in at most their end points, where
+// the longer length wins.  Walking l downwards gives every length its "class":
+// the prefixes whose widest code has that length, with subtables of 2^(l -
+// mainbits) entries laid out consecutively.  No per-prefix scratch is needed.
 // ---------------------------------------------------------------------------
-template <int T>
-__device__ __noinline__ bool build_table(uint32_t *table, const uint8_t *lens, uint32_t nsyms, int tablebits,
-                            uint32_t cap, bool litlen, StreamLds &L, int lig, int gshift) {
-  const uint32_t main_size = 1u << tablebits;
+enum : int { BUILD_OK = 0, BUILD_REJECT = 1, BUILD_NOFIT = 2 };
+
+template <int T, class F>
+__device__ __noinline__ int build_table(typename F::entry_t *table, const uint8_t *lens,
+                                        uint32_t nsyms, bool litlen, StreamLds<F> &L, int lig,
+                                        int gshift) {
+  const int      mainbits  = litlen ? F::LIT_BITS : F::DIST_BITS;
+  const uint32_t cap       = litlen ? F::LIT_CAP : F::DIST_CAP;
+  const int      ref_bits  = litlen ? REF_LIT_BITS : REF_DIST_BITS;
+  const uint32_t ref_cap   = litlen ? REF_LIT_CAP : REF_DIST_CAP;
+  const uint32_t main_size = 1u << mainbits;
   const uint64_t gmask     = (T == 64) ? ~0ull : (((1ull << T) - 1ull) << gshift);
 
   group_sync();
-  for (uint32_t i = lig; i < cap; i += T) table[i] = 0;
   for (int i = lig; i < 16; i += T) L.count[i] = 0;
-  if (lig == 0) L.used = main_size;
   group_sync();
-
   for (uint32_t s = lig; s < nsyms; s += T) atomicAdd(&L.count[lens[s]], 1u);
   group_sync();
 
+  // every lane derives the same layout from the histogram; lane 0 publishes it
+  uint32_t used = main_size;
   {
     int      left = 1;
-    uint32_t code = 0, prev_count = 0;             // count[0] is left out: canonical codes
+    uint32_t code = 0, prev = 0, first[16];
+#pragma unroll
     for (int l = 1; l <= 15; l++) {
       uint32_t c = L.count[l];
       left = (left << 1) - (int)c;
-      if (left < 0) return false;
-      code = (code + prev_count) << 1;
-      prev_count = c;
+      if (left < 0) return BUILD_REJECT;
+      code = (code + prev) << 1;                   // count[0] left out: canonical codes
+      prev = c;
+      first[l] = code;
       if (lig == 0) L.next[l] = code;
     }
+    uint32_t ref_used = 1u << ref_bits, ref_claim = 0x7fffffffu, claim = 0x7fffffffu;
+#pragma unroll
+    for (int l = 15; l >= 1; l--) {
+      uint32_t c = L.count[l];
+      if (l > ref_bits && c) {
+        uint32_t lo = first[l] >> (l - ref_bits), hi = (first[l] + c - 1) >> (l - ref_bits);
+        if (hi >= ref_claim) hi = ref_claim - 1;
+        if (hi + 1 > lo) ref_used += (hi + 1 - lo) << (l - ref_bits);
+        ref_claim = lo < ref_claim ? lo : ref_claim;
+      }
+      if (l > mainbits) {
+        uint32_t lo = 1, hi = 0, at = 0;           // empty class
+        if (c) {
+          uint32_t clo = first[l] >> (l - mainbits);
+          uint32_t chi = (first[l] + c - 1) >> (l - mainbits);
+          if (chi >= claim) chi = claim - 1;
+          if (chi + 1 > clo) {
+            lo = clo;
+            hi = chi;
+            at = used;
+            used += (hi + 1 - lo) << (l - mainbits);
+          }
+          claim = clo < claim ? clo : claim;
+        }
+        if (lig == 0) {
+          L.cls_lo[l] = (uint16_t)lo;
+          L.cls_hi[l] = (uint16_t)hi;
+          L.cls_at[l] = (uint16_t)(at < 0xffffu ? at : 0xffffu);
+        }
+      }
+    }
+    if (ref_used > ref_cap) return BUILD_REJECT;   // infl.c:524-525
+    if (used > cap) return BUILD_NOFIT;
+  }
+
+  for (uint32_t i = lig; i < used; i += T) table[i] = 0;
+  group_sync();
+
+  // main-table entries that point at subtables
+  for (int l = mainbits + 1; l <= 15; l++) {
+    uint32_t lo = L.cls_lo[l], hi = L.cls_hi[l], at = L.cls_at[l];
+    if (hi >= lo)
+      for (uint32_t p = lo + lig; p <= hi; p += T)
+        table[__brev(p) >> (32 - mainbits)] =
+            F::sub_entry(at + ((p - lo) << (l - mainbits)), (uint32_t)(l - mainbits));
   }
   group_sync();
 
-  // canonical codes in symbol order, T symbols per round
+  // canonical codes in symbol order, T symbols per round, entries written at once
   for (uint32_t base = 0; base < nsyms; base += T) {
-    uint32_t s   = base + lig;
-    uint32_t len = s < nsyms ? lens[s] : 0;
+    uint32_t s    = base + lig;
+    uint32_t len  = s < nsyms ? lens[s] : 0;
     uint32_t rank = 0, cnt = 0;
     for (uint32_t l = 1; l <= 15; l++) {
       uint64_t m = __ballot(len == l) & gmask;
@@ -233,42 +393,22 @@ __device__ __noinline__ bool build_table(uint32_t *table, const uint8_t *lens, u
     group_sync();
     if (len) {
       if (rank + 1 == cnt) L.next[len] = code + 1;
+      typename F::entry_t e = litlen ? F::lit_entry(s, len) : F::dist_entry(s, len);
       uint32_t r = __brev(code) >> (32 - len);
-      L.rev[s] = (uint16_t)r;
-      if (len > (uint32_t)tablebits)               // subtable width wanted under this prefix
-        atomicMax(&table[r & (main_size - 1u)], len - tablebits);
+      if (e) {
+        if (len <= (uint32_t)mainbits) {
+          for (uint32_t i = r; i < main_size; i += 1u << len) table[i] = e;
+        } else {
+          uint32_t me  = table[r & (main_size - 1u)];
+          uint32_t at  = F::sub_at(me);
+          uint32_t end = 1u << F::sub_bits(me);
+          for (uint32_t i = r >> mainbits; i < end; i += 1u << (len - mainbits)) table[at + i] = e;
+        }
+      }
     }
     group_sync();
   }
-
-  // turn the widths into subtable pointers
-  for (uint32_t p = lig; p < main_size; p += T) {
-    uint32_t w = table[p];
-    if (w) {
-      uint32_t at = atomicAdd(&L.used, 1u << w);
-      table[p] = (at << 16) | E_SUB | (w << 5) | (uint32_t)tablebits;
-    }
-  }
-  group_sync();
-  if (L.used > cap) return false;
-
-  for (uint32_t s = lig; s < nsyms; s += T) {
-    uint32_t len = lens[s];
-    if (!len) continue;
-    uint32_t e = litlen ? litlen_entry(s, len) : dist_entry(s, len);
-    if (!e) continue;
-    uint32_t r = L.rev[s];
-    if (len <= (uint32_t)tablebits) {
-      for (uint32_t i = r; i < main_size; i += 1u << len) table[i] = e;
-    } else {
-      uint32_t me  = table[r & (main_size - 1u)];
-      uint32_t at  = me >> 16;
-      uint32_t end = 1u << ((me >> 5) & 15u);
-      for (uint32_t i = r >> tablebits; i < end; i += 1u << (len - tablebits)) table[at + i] = e;
-    }
-  }
-  group_sync();
-  return true;
+  return BUILD_OK;
 }
 
 // 256-entry direct table for the 19-symbol code-length alphabet: the job the
@@ -317,19 +457,23 @@ __device__ __noinline__ bool build_clen_table(uint16_t *tab, uint64_t packed, in
 }
 
 // Fixed-Huffman code lengths (apicommon.h:53-64) into L.lens, then both tables.
-template <int T>
-__device__ __noinline__ bool setup_fixed(StreamLds &L, int lig, int gshift) {
+template <int T, class F>
+__device__ __noinline__ int setup_fixed(StreamLds<F> &L, int lig, int gshift) {
   group_sync();
   for (int s = lig; s < 320; s += T)
     L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
-  return build_table<T>(L.lit, L.lens, 288, LIT_BITS, LIT_CAP, true, L, lig, gshift) &&
-         build_table<T>(L.dist, L.lens + 288, 32, DIST_BITS, DIST_CAP, false, L, lig, gshift);
+  int rc = build_table<T, F>(L.lit, L.lens, 288, true, L, lig, gshift);
+  if (rc == BUILD_OK) rc = build_table<T, F>(L.dist, L.lens + 288, 32, false, L, lig, gshift);
+  return rc;
 }
 
 // Dynamic block header (rules of infl.c:903-1000, including "at least 7 bits
-// must be left before every code-length symbol", :947).
-template <int T>
-__device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds &L, int lig, int gshift) {
+// must be left before every code-length symbol", :947).  Returns INFL_D_* or
+// INFL_D_NOFIT.
+constexpr int INFL_D_NOFIT = 100;   // valid so far, but the tables exceed the compact format
+
+template <int T, class F>
+__device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds<F> &L, int lig, int gshift) {
   rd_fill(r);
   if (r.n < 14) return INFL_D_NEED_INPUT;
   uint32_t hlit  = ((uint32_t)r.bits & 31u) + 257u;
@@ -350,7 +494,7 @@ __device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds &L, int lig, i
     rd_drop(r, 3);
   }
 
-  uint16_t *ctab = L.rev;                          // 256 entries fit in rev[320]
+  uint16_t *ctab = (uint16_t *)L.dist;             // the distance table is built later
   if (!build_clen_table<T>(ctab, packed, lig)) return INFL_D_INVALID;
 
   for (int s = lig; s < 320; s += T) L.lens[s] = 0;
@@ -393,15 +537,15 @@ __device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds &L, int lig, i
     }
   }
 
-  if (!build_table<T>(L.lit, L.lens, hlit, LIT_BITS, LIT_CAP, true, L, lig, gshift) ||
-      !build_table<T>(L.dist, L.lens + hlit, hdist, DIST_BITS, DIST_CAP, false, L, lig, gshift))
-    return INFL_D_INVALID;
-  return INFL_D_OK;
+  int rc = build_table<T, F>(L.lit, L.lens, hlit, true, L, lig, gshift);
+  if (rc == BUILD_OK) rc = build_table<T, F>(L.dist, L.lens + hlit, hdist, false, L, lig, gshift);
+  return rc == BUILD_OK ? INFL_D_OK : rc == BUILD_REJECT ? INFL_D_INVALID : INFL_D_NOFIT;
 }
 
 // Stored block reached through the block loop (rules of infl.c:659-715).
 template <int T>
-__device__ __forceinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap, int lig) {
+__device__ __forceinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
+                                            int lig) {
   rd_drop(r, r.n & 7u);
   rd_fill(r);
   if (r.n < 32) return INFL_D_NEED_INPUT;
@@ -419,42 +563,43 @@ __device__ __forceinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &p
 }
 
 // One Huffman-coded block (rules of infl.c:717-901).
-template <int T>
+template <int T, class F>
 __device__ __forceinline__ int huffman_block(Reader &r, uint8_t *dst, uint32_t &pos_io, uint32_t cap,
-                             const StreamLds &L, int lig, uint64_t &fuel) {
+                                             const StreamLds<F> &L, int lig, uint64_t &fuel) {
   uint32_t pos = pos_io;
+  int      rc  = INFL_D_OK;
   for (;;) {
-    if (fuel-- == 0) return INFL_D_INTERNAL;
+    if (fuel-- == 0) { rc = INFL_D_INTERNAL; break; }
     rd_fill(r);
-    uint32_t e = tab_lookup(L.lit, LIT_BITS, (uint32_t)r.bits);
-    if (!e) return INFL_D_INVALID;
-    uint32_t total = e & 31u;
-    if (r.n < total) return INFL_D_NEED_INPUT;
+    Sym s = F::lit_sym(tab_lookup<F>(L.lit, F::LIT_BITS, (uint32_t)r.bits));
+    if (s.kind == K_INVALID) { rc = INFL_D_INVALID; break; }
+    uint32_t total = s.codelen + s.xbits;
+    if (r.n < total) { rc = INFL_D_NEED_INPUT; break; }
 
-    if (e & E_LITERAL) {
+    if (s.kind == K_LITERAL) {
       rd_drop(r, total);
-      if (pos >= cap) return INFL_D_FULL;
-      if (lig == 0) dst[pos] = (uint8_t)(e >> 16);
+      if (pos >= cap) { rc = INFL_D_FULL; break; }
+      if (lig == 0) dst[pos] = (uint8_t)s.base;
       pos++;
       continue;
     }
-    if (e & E_END) {
+    if (s.kind == K_END) {
       rd_drop(r, total);
       break;
     }
-    uint32_t len = (e >> 16) + (((uint32_t)r.bits & ((1u << total) - 1u)) >> ((e >> 5) & 15u));
+    uint32_t len = s.base + (((uint32_t)r.bits & ((1u << total) - 1u)) >> s.codelen);
     rd_drop(r, total);
 
     rd_fill(r);
-    e = tab_lookup(L.dist, DIST_BITS, (uint32_t)r.bits);
-    if (!e) return INFL_D_INVALID;
-    total = e & 31u;
-    if (r.n < total) return INFL_D_NEED_INPUT;
-    uint32_t dist = (e >> 16) + (((uint32_t)r.bits & ((1u << total) - 1u)) >> ((e >> 5) & 15u));
+    Sym d = F::dist_sym(tab_lookup<F>(L.dist, F::DIST_BITS, (uint32_t)r.bits));
+    if (d.kind == K_INVALID) { rc = INFL_D_INVALID; break; }
+    total = d.codelen + d.xbits;
+    if (r.n < total) { rc = INFL_D_NEED_INPUT; break; }
+    uint32_t dist = d.base + (((uint32_t)r.bits & ((1u << total) - 1u)) >> d.codelen);
     rd_drop(r, total);
 
-    if (!dist || dist > pos) return INFL_D_INVALID;
-    if (len > cap - pos) return INFL_D_FULL;
+    if (!dist || dist > pos) { rc = INFL_D_INVALID; break; }
+    if (len > cap - pos) { rc = INFL_D_FULL; break; }
 
     // literal stores of lane 0 and earlier match stores must be ordered before
     // the loads below for the compiler too (the hardware keeps issue order)
@@ -464,13 +609,13 @@ __device__ __forceinline__ int huffman_block(Reader &r, uint8_t *dst, uint32_t &
     pos += len;
   }
   pos_io = pos;
-  return INFL_D_OK;
+  return rc;
 }
 
 // Block loop (infl.c:1063-1092).
-template <int T>
-__device__ int block_loop(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap, StreamLds &L,
-                          int lig, int gshift, uint64_t &fuel) {
+template <int T, class F>
+__device__ __forceinline__ int block_loop(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
+                                          StreamLds<F> &L, int lig, int gshift, uint64_t &fuel) {
   bool     fixed_ready = false;
   uint32_t bfinal = 0;
   while (!bfinal) {
@@ -483,18 +628,21 @@ __device__ int block_loop(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap, 
     int rc;
     if (btype == 0) {
       rc = stored_block<T>(r, dst, pos, cap, lig);
-    } else if (btype == 1) {
-      if (!fixed_ready) {
-        if (!setup_fixed<T>(L, lig, gshift)) return INFL_D_INTERNAL;
-        fixed_ready = true;
-      }
-      rc = huffman_block<T>(r, dst, pos, cap, L, lig, fuel);
-    } else if (btype == 2) {
-      fixed_ready = false;
-      rc = setup_dynamic<T>(r, L, lig, gshift);
-      if (rc == INFL_D_OK) rc = huffman_block<T>(r, dst, pos, cap, L, lig, fuel);
-    } else {
+    } else if (btype == 3) {
       rc = INFL_D_INVALID;
+    } else {
+      if (btype == 1) {
+        rc = INFL_D_OK;
+        if (!fixed_ready) {
+          int b = setup_fixed<T, F>(L, lig, gshift);
+          rc = b == BUILD_OK ? INFL_D_OK : b == BUILD_NOFIT ? INFL_D_NOFIT : INFL_D_INTERNAL;
+          fixed_ready = rc == INFL_D_OK;
+        }
+      } else {
+        fixed_ready = false;
+        rc = setup_dynamic<T, F>(r, L, lig, gshift);
+      }
+      if (rc == INFL_D_OK) rc = huffman_block<T, F>(r, dst, pos, cap, L, lig, fuel);
     }
     if (rc != INFL_D_OK) return rc;
   }
@@ -511,10 +659,11 @@ __device__ __forceinline__ bool zlib_header_ok(const uint8_t *p) {   // infl.c:2
 // after infl(); `pos` is the output position actually reached and `cur` the
 // first input byte with unread bits (both also valid when the stream stopped
 // early; the incremental API reports them).
-template <int T>
-__device__ int inflate_stream(const uint8_t *src, uint32_t srclen, uint8_t *dst, uint32_t cap,
-                              bool zlib, StreamLds &L, int lig, int gshift, uint32_t &outlen,
-                              uint32_t &pos, const uint8_t *&cur) {
+template <int T, class F>
+__device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srclen, uint8_t *dst,
+                                              uint32_t cap, bool zlib, StreamLds<F> &L, int lig,
+                                              int gshift, uint32_t &outlen, uint32_t &pos,
+                                              const uint8_t *&cur) {
   outlen = 0;
   pos    = 0;
   cur    = src;
@@ -565,15 +714,20 @@ __device__ int inflate_stream(const uint8_t *src, uint32_t srclen, uint8_t *dst,
     p += 2;
   }
   rd_seek(r, p);
-  rc  = block_loop<T>(r, dst, pos, cap, L, lig, gshift, fuel);
+  rc  = block_loop<T, F>(r, dst, pos, cap, L, lig, gshift, fuel);
   cur = rd_byte_ptr(r);
   if (rc == INFL_D_OK) outlen = pos;
   return rc;
 }
 
-// flags: bit 0 = zlib wrapper (INFL_ZLIB); bit 8 = publish the position reached
-// in `outlen` even when the stream stopped early (incremental API).
-template <int T>
+// flags: bit 0 = zlib wrapper (INFL_ZLIB); INFL_F_PROGRESS = publish the position
+// reached in `outlen` even when the stream stopped early (incremental API).
+//
+// MODE 0: decode every stream and write its result.
+// MODE 1: first pass with the compact tables.  A stream that completes writes
+//         its result; any other stream is marked INFL_STATUS_DEFERRED.
+// MODE 2: second pass: only streams marked INFL_STATUS_DEFERRED are decoded.
+template <int T, class F, int MODE>
 __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restrict__ src,
                                                         const uint64_t *__restrict__ src_off,
                                                         uint8_t *__restrict__ dst,
@@ -584,7 +738,7 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
                                                         int32_t *__restrict__ detail,
                                                         uint32_t *__restrict__ inpos) {
   constexpr int G = 64 / T;                        // streams per wavefront
-  __shared__ StreamLds lds[G];
+  __shared__ StreamLds<F> lds[G];
 
   const int      lane   = threadIdx.x;
   const int      group  = lane / T;
@@ -592,16 +746,21 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
   const int      gshift = group * T;
   const uint64_t i      = (uint64_t)blockIdx.x * G + group;
   if (i >= n) return;
+  if (MODE == 2 && status[i] != INFL_STATUS_DEFERRED) return;
 
   const uint64_t s0 = src_off[i], s1 = src_off[i + 1];
   const uint64_t d0 = dst_off[i], d1 = dst_off[i + 1];
   uint32_t       out = 0, pos = 0;
   const uint8_t *cur = nullptr;
-  int rc = inflate_stream<T>(src + s0, (uint32_t)(s1 - s0), dst + d0, (uint32_t)(d1 - d0),
-                             (flags & 0xff) == 1, lds[group], lig, gshift, out, pos, cur);
+  int rc = inflate_stream<T, F>(src + s0, (uint32_t)(s1 - s0), dst + d0, (uint32_t)(d1 - d0),
+                                (flags & 0xff) == 1, lds[group], lig, gshift, out, pos, cur);
   if (lig == 0) {
+    if (MODE == 1 && rc != INFL_D_OK) {
+      status[i] = INFL_STATUS_DEFERRED;
+      return;
+    }
     status[i] = rc == INFL_D_OK ? 0 : -1;          // every failure is UNZ_ERR (infl.c:1074-1087)
-    outlen[i] = ((flags & 0x100) && rc != INFL_D_OK && rc != INFL_D_INVALID) ? pos : out;
+    outlen[i] = ((flags & INFL_F_PROGRESS) && rc != INFL_D_OK && rc != INFL_D_INVALID) ? pos : out;
     if (detail) detail[i] = rc;
     if (inpos) inpos[i] = (uint32_t)(cur - (src + s0));
   }
@@ -609,24 +768,35 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
 
 }  // namespace defl
 
+// variant 0: reference-geometry tables only (one launch).
+// variant 1: compact tables first, reference-geometry tables for what they defer (two launches).
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                                  uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
-                                 void *stream) {
+                                 int variant, void *stream) {
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   auto s = (const uint8_t *)src;
   auto d = (uint8_t *)dst;
-#define LAUNCH(T)                                                                              \
-  hipLaunchKernelGGL(defl::infl_batch_kernel<T>, dim3((unsigned)((n + (64 / T) - 1) / (64 / T))), \
-                     dim3(64), 0, st, s, src_off, d, dst_off, flags, n, status, outlen, detail, inpos)
+#define LAUNCH(T, FMT, MODE)                                                                   \
+  hipLaunchKernelGGL((defl::infl_batch_kernel<T, defl::FMT, MODE>),                            \
+                     dim3((unsigned)((n + (64 / T) - 1) / (64 / T))), dim3(64), 0, st, s, src_off, \
+                     d, dst_off, flags, n, status, outlen, detail, inpos)
+#define LAUNCH_T(T)             \
+  if (variant == 0) {           \
+    LAUNCH(T, RefFmt, 0);       \
+  } else {                      \
+    LAUNCH(T, CompactFmt, 1);   \
+    LAUNCH(T, RefFmt, 2);       \
+  }
   switch (lanes) {
-    case 64: LAUNCH(64); break;
-    case 32: LAUNCH(32); break;
-    case 16: LAUNCH(16); break;
-    case 8:  LAUNCH(8);  break;
+    case 64: LAUNCH_T(64) break;
+    case 32: LAUNCH_T(32) break;
+    case 16: LAUNCH_T(16) break;
+    case 8:  LAUNCH_T(8)  break;
     default: return -1;
   }
+#undef LAUNCH_T
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

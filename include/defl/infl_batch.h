@@ -102,6 +102,15 @@ UNZ_EXPORT int   infl_gpu_sync(void);
 UNZ_EXPORT int
 infl_gpu_set_lanes_per_stream(int lanes);
 
+/* Tuning knob for measurements: 0 = one launch with decode tables in the
+   reference's geometry (32-bit entries, 10 KiB of LDS per stream); 1 = a first
+   launch with compact 16-bit tables (2.7 KiB per stream, four times the streams
+   in flight) plus a second launch in the reference's geometry for the streams
+   the first one could not finish.  Results are identical.  Returns the value
+   in effect. */
+UNZ_EXPORT int
+infl_gpu_set_table_variant(int variant);
+
 #ifdef __cplusplus
 }
 #endif

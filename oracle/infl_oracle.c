@@ -297,6 +297,14 @@ stored_in_stream(rd_t *r, uint8_t *dst, size_t *dpos, size_t cap) {
   return ORACLE_D_OK;
 }
 
+/* optional observer of dynamic headers (statistics for table sizing experiments) */
+static void (*g_header_hook)(const uint8_t *lens, unsigned hlit, unsigned hdist);
+
+void
+oracle_set_header_hook(void (*hook)(const uint8_t *, unsigned, unsigned)) {
+  g_header_hook = hook;
+}
+
 /* dynamic block header (infl.c:903-1000) */
 static int
 dynamic_header(rd_t *r, tabs_t *t) {
@@ -358,6 +366,7 @@ dynamic_header(rd_t *r, tabs_t *t) {
     }
   }
 
+  if (g_header_hook) g_header_hook(lens, hlit, hdist);
   if (oracle_table_build(t->lit, &used, lens, hlit, LIT_BITS, LIT_CAP, 1) != 0 ||
       oracle_table_build(t->dist, &used, lens + hlit, hdist, DIST_BITS, DIST_CAP, 0) != 0)
     return ORACLE_D_INVALID;

@@ -56,12 +56,13 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
 
 extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
                               int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
-                              uint32_t *inpos, int lanes) {
+                              uint32_t *inpos, int lanes, int variant) {
   emu::g_lanes_per_group = lanes;
-  return infl_launch_batch(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, nullptr);
+  return infl_launch_batch(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, variant,
+                           nullptr);
 }
 
-// emu_run <in.bin> <out.bin> <lanes> <flags>
+// emu_run <in.bin> <out.bin> <lanes> <flags> <variant>
 //   in : u64 n, u64 src_off[n+1], u64 dst_off[n+1], src bytes
 //   out: i32 status[n], u32 outlen[n], i32 detail[n], u32 inpos[n], dst bytes
 // The arenas are allocated with their exact sizes so that AddressSanitizer sees any access
@@ -70,7 +71,7 @@ extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *ds
 #include <stdlib.h>
 
 int main(int argc, char **argv) {
-  if (argc < 5) return 2;
+  if (argc < 6) return 2;
   FILE *f = fopen(argv[1], "rb");
   if (!f) return 2;
   uint64_t n = 0;
@@ -84,7 +85,7 @@ int main(int argc, char **argv) {
   std::vector<int32_t>  status(n, -99), detail(n, -99);
   std::vector<uint32_t> outlen(n, 0), inpos(n, 0);
   int rc = emu_infl_batch(src, so.data(), dst, dof.data(), atoi(argv[4]), n, status.data(), outlen.data(),
-                          detail.data(), inpos.data(), atoi(argv[3]));
+                          detail.data(), inpos.data(), atoi(argv[3]), atoi(argv[5]));
   if (rc != 0) return 3;
   f = fopen(argv[2], "wb");
   fwrite(status.data(), 4, n, f);

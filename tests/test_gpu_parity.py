@@ -19,6 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DATA = os.path.join(HERE, "golden", "defl_testdata")
 ALL = sorted(os.listdir(os.path.join(DATA, "compressed")))
 PAIRS = [f for f in ALL if os.path.exists(os.path.join(DATA, "raw", f))]
+DEFAULT_VARIANT = 0
+VARIANTS = [(64, 0), (32, 0), (16, 0), (8, 0), (64, 1), (32, 1), (16, 1), (8, 1)]
 
 
 def _read(kind, name):
@@ -26,11 +28,12 @@ def _read(kind, name):
         return f.read()
 
 
-def _check_batch(engine, oracle, streams, caps, flags, lanes=64, what=""):
+def _check_batch(engine, oracle, streams, caps, flags, lanes=64, what="", variant=0):
     """Runs one batch on the GPU (device-resident path) and on the oracle; compares everything."""
     src, src_off, dst_off = wl.pack(streams, caps)
     want_dst, want_status, want_outlen = oracle.infl_batch(src, src_off, dst_off, flags)
     assert engine.lib.infl_gpu_set_lanes_per_stream(lanes) == lanes
+    assert engine.lib.infl_gpu_set_table_variant(variant) == variant
     b = engine.device_batch(src, src_off, dst_off)
     try:
         b.run(flags)
@@ -38,6 +41,7 @@ def _check_batch(engine, oracle, streams, caps, flags, lanes=64, what=""):
     finally:
         b.free()
         engine.lib.infl_gpu_set_lanes_per_stream(64)
+        engine.lib.infl_gpu_set_table_variant(DEFAULT_VARIANT)
     bad = np.nonzero((status != want_status) | (outlen != want_outlen))[0]
     assert bad.size == 0, (what, "stream", int(bad[0]), int(status[bad[0]]), int(want_status[bad[0]]),
                            int(outlen[bad[0]]), int(want_outlen[bad[0]]), int(detail[bad[0]]))
@@ -63,11 +67,11 @@ def test_file_pair_infl_buf(engine, name):
     assert pos == len(raw) and out == raw
 
 
-@pytest.mark.parametrize("lanes", [64, 32, 16, 8])
-def test_all_fixtures_one_batch(engine, oracle, lanes):
+@pytest.mark.parametrize("lanes,variant", VARIANTS)
+def test_all_fixtures_one_batch(engine, oracle, lanes, variant):
     streams = [_read("compressed", n) for n in ALL]
     caps = [len(_read("raw", n)) + 1000 if n in PAIRS else 70000 for n in ALL]
-    status, outlen, _ = _check_batch(engine, oracle, streams, caps, 0, lanes, "fixtures")
+    status, outlen, _ = _check_batch(engine, oracle, streams, caps, 0, lanes, "fixtures", variant)
     for n, s, o in zip(ALL, status, outlen):
         if n in PAIRS:
             assert s == 0 and o == len(_read("raw", n)), n
@@ -115,9 +119,9 @@ def _zlib_cases(seed):
                     yield raw, level, strategy
 
 
-@pytest.mark.parametrize("lanes", [64, 32, 16, 8])
+@pytest.mark.parametrize("lanes,variant", VARIANTS)
 @pytest.mark.parametrize("wrap", [0, 1])
-def test_zlib_streams_batch(engine, oracle, wrap, lanes):
+def test_zlib_streams_batch(engine, oracle, wrap, lanes, variant):
     """Valid streams of every block type; exact capacity, one byte short, generous."""
     streams, caps, raws = [], [], []
     for raw, level, strategy in _zlib_cases(7 + wrap):
@@ -126,7 +130,7 @@ def test_zlib_streams_batch(engine, oracle, wrap, lanes):
             streams.append(comp)
             caps.append(cap)
             raws.append(raw)
-    status, outlen, detail = _check_batch(engine, oracle, streams, caps, wrap, lanes, "zlib")
+    status, outlen, detail = _check_batch(engine, oracle, streams, caps, wrap, lanes, "zlib", variant)
     for i, raw in enumerate(raws):
         if caps[i] >= len(raw):
             assert status[i] == 0 and outlen[i] == len(raw)
@@ -134,8 +138,8 @@ def test_zlib_streams_batch(engine, oracle, wrap, lanes):
             assert status[i] == -1 and detail[i] == capi.D_FULL
 
 
-@pytest.mark.parametrize("lanes", [64, 16])
-def test_fuzz_mutations_and_truncations(engine, oracle, lanes):
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (64, 1), (16, 1), (8, 1)])
+def test_fuzz_mutations_and_truncations(engine, oracle, lanes, variant):
     """Differential fuzz against the oracle on malformed input: flipped bits, truncation,
     random bytes.  Return code, output position and bytes must match stream by stream."""
     rng = random.Random(4242)
@@ -165,7 +169,7 @@ def test_fuzz_mutations_and_truncations(engine, oracle, lanes):
         streams.append(bytes(b))
     caps = [rng.choice([0, 10, 1000, 40000, 80000]) for _ in streams]
     for flags in (0, 1):
-        _check_batch(engine, oracle, streams, caps, flags, lanes, "fuzz flags=%d" % flags)
+        _check_batch(engine, oracle, streams, caps, flags, lanes, "fuzz flags=%d" % flags, variant)
 
 
 def test_dynamic_header_edge_cases(engine, oracle):
@@ -174,8 +178,8 @@ def test_dynamic_header_edge_cases(engine, oracle):
     from tests.deflate_builder import header_cases
     streams = header_cases()
     caps = [4096] * len(streams)
-    _check_batch(engine, oracle, streams, caps, 0, 64, "headers")
-    _check_batch(engine, oracle, streams, caps, 0, 8, "headers")
+    for lanes, variant in VARIANTS:
+        _check_batch(engine, oracle, streams, caps, 0, lanes, "headers", variant)
 
 
 def test_text_batch_roundtrip_full_size(engine, oracle):

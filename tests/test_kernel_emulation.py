@@ -23,10 +23,10 @@ def _read(kind, name):
         return f.read()
 
 
-def _compare(oracle, streams, caps, flags, lanes):
+def _compare(oracle, streams, caps, flags, lanes, variant=0):
     src, src_off, dst_off = wl.pack(streams, caps)
     want_dst, want_status, want_outlen = oracle.infl_batch(src, src_off, dst_off, flags)
-    dst, status, outlen, detail, inpos = emu_lib.run(src, src_off, dst_off, flags, lanes)
+    dst, status, outlen, detail, inpos = emu_lib.run(src, src_off, dst_off, flags, lanes, variant)
     for i in range(len(streams)):
         assert status[i] == want_status[i] and outlen[i] == want_outlen[i], \
             (i, int(status[i]), int(want_status[i]), int(outlen[i]), int(want_outlen[i]), int(detail[i]))
@@ -39,22 +39,22 @@ def _compare(oracle, streams, caps, flags, lanes):
     return status, outlen, detail
 
 
-@pytest.mark.parametrize("lanes", [64, 8])
-def test_emulated_kernel_on_fixtures(oracle, lanes):
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (8, 0), (16, 1), (64, 1)])
+def test_emulated_kernel_on_fixtures(oracle, lanes, variant):
     names = [n for n in ALL if os.path.getsize(os.path.join(DATA, "compressed", n)) < 40000]
     streams = [_read("compressed", n) for n in names]
     caps = [(len(_read("raw", n)) + 1000) if os.path.exists(os.path.join(DATA, "raw", n)) else 70000
             for n in names]
-    status, outlen, _ = _compare(oracle, streams, caps, 0, lanes)
+    status, outlen, _ = _compare(oracle, streams, caps, 0, lanes, variant)
     for n, s in zip(names, status):
         if os.path.exists(os.path.join(DATA, "raw", n)):
             assert s == 0, n
 
 
-@pytest.mark.parametrize("lanes", [64, 16])
-def test_emulated_kernel_on_header_cases(oracle, lanes):
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (8, 1), (32, 1)])
+def test_emulated_kernel_on_header_cases(oracle, lanes, variant):
     streams = header_cases()
-    _compare(oracle, streams, [4096] * len(streams), 0, lanes)
+    _compare(oracle, streams, [4096] * len(streams), 0, lanes, variant)
 
 
 def test_emulated_kernel_zlib_and_fuzz(oracle):
@@ -64,6 +64,7 @@ def test_emulated_kernel_zlib_and_fuzz(oracle):
             for lvl, strat in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY))]
     caps = [len(r) for r in raws for _ in range(3)]
     _compare(oracle, good, caps, 1, 32)
+    _compare(oracle, good, caps, 1, 16, 1)
     _compare(oracle, good, [max(0, c - 1) for c in caps], 1, 64)
     bad = []
     for t in range(160):
@@ -77,3 +78,4 @@ def test_emulated_kernel_zlib_and_fuzz(oracle):
         bad.append(bytes(b))
     _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 64)
     _compare(oracle, bad, [8000] * len(bad), 0, 8)
+    _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 8, 1)
