@@ -79,7 +79,9 @@ def main():
     ap.add_argument("--pool", type=int, default=int(os.environ.get("DEFL_BENCH_POOL", 2048)),
                     help="distinct streams generated per GPU; the batch tiles them into distinct "
                          "source and destination slots")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("DEFL_BENCH_LANES", 64)))
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("DEFL_BENCH_LANES", 16)))
+    ap.add_argument("--variant", type=int, default=int(os.environ.get("DEFL_BENCH_VARIANT", 1)),
+                    help="0 = tables in the reference geometry, 1 = compact tables + deferred pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -105,6 +107,7 @@ def main():
     if eng.lib.infl_gpu_init(local) != 0:
         raise SystemExit("infl_gpu_init failed")
     eng.lib.infl_gpu_set_lanes_per_stream(args.lanes)
+    eng.lib.infl_gpu_set_table_variant(args.variant)
 
     n, pool = args.streams, min(args.pool, args.streams)
     workers = max(1, min(8, (os.cpu_count() or 8) // max(1, world)))
@@ -217,6 +220,7 @@ def main():
                 "stream_bytes": STREAM_BYTES,
                 "compressed_ratio": round(comp_bytes / out_bytes, 4),
                 "lanes_per_stream": args.lanes,
+                "table_variant": args.variant,
                 "parallelism": "stream-shard x%d, no data-path collective" % world,
                 "bit_exact_vs_oracle": True,
             },

@@ -17,8 +17,8 @@
 namespace {
 
 std::mutex g_mu;            // guards the cached workspace below
-int        g_lanes = 64;    // lanes of a wavefront per stream
-int        g_variant = 0;   // 0 reference-geometry tables, 1 compact tables + deferred pass
+int        g_lanes = 16;    // lanes of a wavefront per stream
+int        g_variant = 1;   // 0 reference-geometry tables, 1 compact tables + deferred pass
 
 struct Buf {
   void  *p   = nullptr;

@@ -154,18 +154,26 @@ struct CompactFmt {
   }
 };
 
-// Per-stream working set in LDS.
+// Per-stream working set in LDS.  Two regions do double duty while a block
+// is being set up, so that no separate scratch is needed:
+//   * the literal table region first holds the 256-entry (16-bit) table of the
+//     code-length alphabet while the header is read;
+//   * the distance table region holds the block's code lengths (up to 320
+//     bytes) until the literal table is built; the (at most 32) distance code
+//     lengths then move to registers and the distance table takes the region.
 template <class F>
 struct StreamLds {
   typename F::entry_t lit[F::LIT_CAP];
-  typename F::entry_t dist[F::DIST_CAP];   // also holds the 256-entry (16-bit) table of the
-                                           // code-length alphabet while a header is read
-  uint8_t  lens[320];                      // code lengths of the block being set up
+  typename F::entry_t dist[F::DIST_CAP];
   uint32_t count[16];                      // symbols per code length
   uint32_t next[16];                       // next canonical code per length
   uint16_t cls_lo[16], cls_hi[16], cls_at[16];   // subtable classes per code length
+
+  __device__ __forceinline__ uint8_t  *lens() { return (uint8_t *)dist; }
+  __device__ __forceinline__ uint16_t *ctab() { return (uint16_t *)lit; }
 };
-static_assert(sizeof(CompactFmt::entry_t) * CompactFmt::DIST_CAP >= 512, "code-length table must fit");
+static_assert(sizeof(CompactFmt::entry_t) * CompactFmt::LIT_CAP >= 512, "code-length table must fit");
+static_assert(sizeof(CompactFmt::entry_t) * CompactFmt::DIST_CAP >= 320, "code lengths must fit");
 static_assert(CompactFmt::LIT_CAP / 2 <= 512 && CompactFmt::DIST_CAP / 2 <= 512, "9-bit subtable offsets");
 
 // Lanes of a group run in lockstep inside one wavefront; LDS and global
@@ -232,6 +240,86 @@ __device__ __forceinline__ void rd_drop(Reader &r, uint32_t k) {
 // first input byte that still has unread bits
 __device__ __forceinline__ const uint8_t *rd_byte_ptr(const Reader &r) { return r.p - (r.n >> 3); }
 
+// Reader of the compact-table pass.  The group keeps a window of 4 * T input
+// bytes in registers (lane j holds word j) plus the next window, prefetched one
+// window ahead with one coalesced load per lane.  A refill takes its word from
+// the window with a cross-lane read (ds_bpermute: no memory access, no vmcnt
+// wait), so the only global loads inside the symbol loop are the match copies.
+// Every word is loaded from inside the stream (at min(offset, ilen - 4)) and
+// shifted into place when used, so the tail needs no byte loop and nothing
+// past the stream's last byte is ever read.  Needs ilen >= 4; shorter streams
+// are left to the other reader.
+template <int T>
+struct FastReader {
+  const uint8_t *src;
+  uint32_t       ilen, ilen4;   // stream length, and length - 4
+  uint32_t       ipos;          // first input byte not yet moved into `bits`
+  uint64_t       bits;
+  uint32_t       n;
+  uint32_t       wbase;         // stream offset of the current window
+  uint32_t       cur;           // this lane's word of the current window
+  uint32_t       nxt, nxtsh;    // its word of the next window, and the shift still to apply
+  int            lig, gshift;
+};
+
+template <int T>
+__device__ __forceinline__ void rd_load_next(FastReader<T> &r) {
+  uint32_t off = r.wbase + 4u * T + 4u * (uint32_t)r.lig;
+  uint32_t q   = off < r.ilen4 ? off : r.ilen4;
+  __builtin_memcpy(&r.nxt, r.src + q, 4);
+  uint32_t d = off - q;                              // 0 inside the stream
+  r.nxtsh = d >= 4 ? 32u : d * 8;
+}
+
+template <int T>
+__device__ __forceinline__ void rd_promote(FastReader<T> &r) {
+  r.cur = r.nxtsh >= 32 ? 0u : r.nxt >> r.nxtsh;     // zero padded past the end
+  r.wbase += 4u * T;
+  rd_load_next(r);
+}
+
+template <int T>
+__device__ __forceinline__ void rd_seek(FastReader<T> &r, const uint8_t *p) {
+  r.ipos  = (uint32_t)(p - r.src);
+  r.bits  = 0;
+  r.n     = 0;
+  r.wbase = r.ipos - 4u * T;                         // wraps; rd_promote adds it back
+  rd_load_next(r);
+  rd_promote(r);
+}
+
+template <int T>
+__device__ __forceinline__ void rd_fill(FastReader<T> &r) {
+  if (r.n < 32) {
+    uint32_t k = r.ilen - r.ipos;
+    k = k < 4 ? k : 4;
+    uint32_t idx = (r.ipos - r.wbase) >> 2;          // word of the window, group-uniform
+    if (idx >= (uint32_t)T) {
+      rd_promote(r);
+      idx -= T;
+    }
+    uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r.gshift + idx) << 2), (int)r.cur);
+    w = k ? w : 0u;                                  // nothing left: keep the bits above n zero
+    r.bits |= (uint64_t)w << r.n;
+    r.n    += k * 8;
+    r.ipos += k;
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void rd_drop(FastReader<T> &r, uint32_t k) {
+  r.bits >>= k;
+  r.n    -= k;
+}
+
+template <int T>
+__device__ __forceinline__ const uint8_t *rd_byte_ptr(const FastReader<T> &r) {
+  return r.src + (r.ipos - (r.n >> 3));
+}
+template <int T>
+__device__ __forceinline__ const uint8_t *rd_end(const FastReader<T> &r) { return r.src + r.ilen; }
+__device__ __forceinline__ const uint8_t *rd_end(const Reader &r) { return r.end; }
+
 template <class F>
 __device__ __forceinline__ uint32_t tab_lookup(const typename F::entry_t *tab, int mainbits,
                                                uint32_t bits) {
@@ -296,10 +384,14 @@ __device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t pos, uint32_t 
 // ---------------------------------------------------------------------------
 enum : int { BUILD_OK = 0, BUILD_REJECT = 1, BUILD_NOFIT = 2 };
 
+//
+// Code lengths come from LDS (`lens`) or, when `lens` is null, from `lens_reg`:
+// byte j of that register is the length of symbol lig + j * T (at most 32
+// symbols, the distance alphabet).
 template <int T, class F>
 __device__ __noinline__ int build_table(typename F::entry_t *table, const uint8_t *lens,
-                                        uint32_t nsyms, bool litlen, StreamLds<F> &L, int lig,
-                                        int gshift) {
+                                        uint32_t lens_reg, uint32_t nsyms, bool litlen,
+                                        StreamLds<F> &L, int lig, int gshift) {
   const int      mainbits  = litlen ? F::LIT_BITS : F::DIST_BITS;
   const uint32_t cap       = litlen ? F::LIT_CAP : F::DIST_CAP;
   const int      ref_bits  = litlen ? REF_LIT_BITS : REF_DIST_BITS;
@@ -310,7 +402,8 @@ __device__ __noinline__ int build_table(typename F::entry_t *table, const uint8_
   group_sync();
   for (int i = lig; i < 16; i += T) L.count[i] = 0;
   group_sync();
-  for (uint32_t s = lig; s < nsyms; s += T) atomicAdd(&L.count[lens[s]], 1u);
+  for (uint32_t s = lig, j = 0; s < nsyms; s += T, j++)
+    atomicAdd(&L.count[lens ? lens[s] : (lens_reg >> (8 * j)) & 0xffu], 1u);
   group_sync();
 
   // every lane derives the same layout from the histogram; lane 0 publishes it
@@ -377,9 +470,9 @@ __device__ __noinline__ int build_table(typename F::entry_t *table, const uint8_
   group_sync();
 
   // canonical codes in symbol order, T symbols per round, entries written at once
-  for (uint32_t base = 0; base < nsyms; base += T) {
+  for (uint32_t base = 0, j = 0; base < nsyms; base += T, j++) {
     uint32_t s    = base + lig;
-    uint32_t len  = s < nsyms ? lens[s] : 0;
+    uint32_t len  = s >= nsyms ? 0 : lens ? lens[s] : (lens_reg >> (8 * j)) & 0xffu;
     uint32_t rank = 0, cnt = 0;
     for (uint32_t l = 1; l <= 15; l++) {
       uint64_t m = __ballot(len == l) & gmask;
@@ -456,14 +549,24 @@ __device__ __noinline__ bool build_clen_table(uint16_t *tab, uint64_t packed, in
   return true;
 }
 
-// Fixed-Huffman code lengths (apicommon.h:53-64) into L.lens, then both tables.
+// The (at most 32) distance code lengths lens[first .. first + n) as one register
+// per lane: byte j = length of distance symbol lig + j * T.
+template <int T>
+__device__ __forceinline__ uint32_t dist_lens_to_reg(const uint8_t *lens, uint32_t first, uint32_t n,
+                                                     int lig) {
+  uint32_t v = 0;
+  for (uint32_t s = lig, j = 0; s < n && j < 4; s += T, j++) v |= (uint32_t)lens[first + s] << (8 * j);
+  return v;
+}
+
+// Fixed-Huffman code lengths (apicommon.h:53-64), then both tables.
 template <int T, class F>
 __device__ __noinline__ int setup_fixed(StreamLds<F> &L, int lig, int gshift) {
+  uint8_t *lens = L.lens();
   group_sync();
-  for (int s = lig; s < 320; s += T)
-    L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
-  int rc = build_table<T, F>(L.lit, L.lens, 288, true, L, lig, gshift);
-  if (rc == BUILD_OK) rc = build_table<T, F>(L.dist, L.lens + 288, 32, false, L, lig, gshift);
+  for (int s = lig; s < 288; s += T) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+  int rc = build_table<T, F>(L.lit, lens, 0, 288, true, L, lig, gshift);
+  if (rc == BUILD_OK) rc = build_table<T, F>(L.dist, nullptr, 0x05050505u, 32, false, L, lig, gshift);
   return rc;
 }
 
@@ -472,8 +575,8 @@ __device__ __noinline__ int setup_fixed(StreamLds<F> &L, int lig, int gshift) {
 // INFL_D_NOFIT.
 constexpr int INFL_D_NOFIT = 100;   // valid so far, but the tables exceed the compact format
 
-template <int T, class F>
-__device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds<F> &L, int lig, int gshift) {
+template <int T, class F, class R>
+__device__ __forceinline__ int setup_dynamic(R &r, StreamLds<F> &L, int lig, int gshift) {
   rd_fill(r);
   if (r.n < 14) return INFL_D_NEED_INPUT;
   uint32_t hlit  = ((uint32_t)r.bits & 31u) + 257u;
@@ -494,10 +597,11 @@ __device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds<F> &L, int lig
     rd_drop(r, 3);
   }
 
-  uint16_t *ctab = (uint16_t *)L.dist;             // the distance table is built later
+  uint16_t *ctab = L.ctab();
+  uint8_t  *lens = L.lens();
   if (!build_clen_table<T>(ctab, packed, lig)) return INFL_D_INVALID;
 
-  for (int s = lig; s < 320; s += T) L.lens[s] = 0;
+  for (int s = lig; s < 320; s += T) lens[s] = 0;
   group_sync();
 
   uint32_t prev = 0;
@@ -509,7 +613,7 @@ __device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds<F> &L, int lig
     uint32_t sym = e >> 8;
     rd_drop(r, e & 255u);
     if (sym < 16) {
-      if (lig == 0) L.lens[i] = (uint8_t)sym;
+      if (lig == 0) lens[i] = (uint8_t)sym;
       prev = sym;
       i++;
     } else if (sym == 16) {
@@ -518,7 +622,7 @@ __device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds<F> &L, int lig
       uint32_t rep = 3u + ((uint32_t)r.bits & 3u);
       rd_drop(r, 2);
       if (i + rep > n) return INFL_D_INVALID;
-      if ((uint32_t)lig < rep) L.lens[i + lig] = (uint8_t)prev;   // rep <= 6 <= T
+      if ((uint32_t)lig < rep) lens[i + lig] = (uint8_t)prev;   // rep <= 6 <= T
       i += rep;
     } else if (sym == 17) {
       if (r.n < 3) return INFL_D_NEED_INPUT;
@@ -537,14 +641,17 @@ __device__ __forceinline__ int setup_dynamic(Reader &r, StreamLds<F> &L, int lig
     }
   }
 
-  int rc = build_table<T, F>(L.lit, L.lens, hlit, true, L, lig, gshift);
-  if (rc == BUILD_OK) rc = build_table<T, F>(L.dist, L.lens + hlit, hdist, false, L, lig, gshift);
+  int rc = build_table<T, F>(L.lit, lens, 0, hlit, true, L, lig, gshift);
+  if (rc == BUILD_OK) {
+    uint32_t dl = dist_lens_to_reg<T>(lens, hlit, hdist, lig);
+    rc = build_table<T, F>(L.dist, nullptr, dl, hdist, false, L, lig, gshift);
+  }
   return rc == BUILD_OK ? INFL_D_OK : rc == BUILD_REJECT ? INFL_D_INVALID : INFL_D_NOFIT;
 }
 
 // Stored block reached through the block loop (rules of infl.c:659-715).
-template <int T>
-__device__ __forceinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
+template <int T, class R>
+__device__ __forceinline__ int stored_block(R &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
                                             int lig) {
   rd_drop(r, r.n & 7u);
   rd_fill(r);
@@ -555,7 +662,7 @@ __device__ __forceinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &p
   if (len != (nlen ^ 0xffffu)) return INFL_D_INVALID;
   if (len > cap - pos) return INFL_D_FULL;
   const uint8_t *s = rd_byte_ptr(r);
-  if ((size_t)(r.end - s) < len) return INFL_D_NEED_INPUT;
+  if ((size_t)(rd_end(r) - s) < len) return INFL_D_NEED_INPUT;
   coop_copy<T>(dst + pos, s, len, lig);
   pos += len;
   rd_seek(r, s + len);
@@ -563,13 +670,13 @@ __device__ __forceinline__ int stored_block(Reader &r, uint8_t *dst, uint32_t &p
 }
 
 // One Huffman-coded block (rules of infl.c:717-901).
-template <int T, class F>
-__device__ __forceinline__ int huffman_block(Reader &r, uint8_t *dst, uint32_t &pos_io, uint32_t cap,
+template <int T, class F, class R>
+__device__ __forceinline__ int huffman_block(R &r, uint8_t *dst, uint32_t &pos_io, uint32_t cap,
                                              const StreamLds<F> &L, int lig, uint64_t &fuel) {
+  (void)fuel;   // every turn consumes >= 1 bit of a finite input; blocks are counted by the caller
   uint32_t pos = pos_io;
   int      rc  = INFL_D_OK;
   for (;;) {
-    if (fuel-- == 0) { rc = INFL_D_INTERNAL; break; }
     rd_fill(r);
     Sym s = F::lit_sym(tab_lookup<F>(L.lit, F::LIT_BITS, (uint32_t)r.bits));
     if (s.kind == K_INVALID) { rc = INFL_D_INVALID; break; }
@@ -612,10 +719,98 @@ __device__ __forceinline__ int huffman_block(Reader &r, uint8_t *dst, uint32_t &
   return rc;
 }
 
-// Block loop (infl.c:1063-1092).
-template <int T, class F>
-__device__ __forceinline__ int block_loop(Reader &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
-                                          StreamLds<F> &L, int lig, int gshift, uint64_t &fuel) {
+// Length / distance base values shared by all streams of a workgroup (compact
+// pass): entry = base | extra bits << 16; [0..31] lengths (index = symbol - 257),
+// [32..63] distances.  Saves recomputing them per match.
+struct BaseTab {
+  uint32_t v[64];
+};
+
+// Symbol loop of the compact pass.  Same acceptance as huffman_block(); a stream
+// that stops for any reason is decoded again by the second pass, so the reason
+// is not reported.
+template <int T>
+__device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t *dst, uint32_t &pos_io,
+                                                      uint32_t cap, const uint16_t *lit,
+                                                      const uint16_t *dist, const BaseTab &bt,
+                                                      int lig) {
+  typedef CompactFmt F;
+  constexpr uint32_t NONE = 0xffffffffu;
+  uint32_t pos = pos_io;
+  bool     ok  = false;
+  // The first T bytes of a non-overlapping match are loaded when the match is
+  // decoded and stored when the next match starts (or the block ends), so the
+  // load latency overlaps with the decode of the symbols in between.  Issue order
+  // keeps it exact: the pending store is issued before any later load.
+  uint32_t pend_off = NONE, pend_val = 0;
+  for (;;) {
+    rd_fill(r);
+    uint32_t b = (uint32_t)r.bits;
+    uint32_t e = lit[b & ((1u << F::LIT_BITS) - 1u)];
+    if (e & F::F_SUB) e = lit[F::sub_at(e) + ((b >> F::LIT_BITS) & ((1u << (e & 15u)) - 1u))];
+    uint32_t cl = e & 15u;
+    if (e & F::F_LITERAL) {
+      if (r.n < cl || pos >= cap) break;
+      rd_drop(r, cl);
+      if (lig == 0) dst[pos] = (uint8_t)(e >> 4);
+      pos++;
+      continue;
+    }
+    if (!(e & F::F_BASE)) {                        // end of block, or no code
+      if (e && r.n >= cl) {
+        rd_drop(r, cl);
+        ok = true;
+      }
+      break;
+    }
+    uint32_t lb    = bt.v[(e >> 4) & 31u];
+    uint32_t xb    = lb >> 16;
+    uint32_t total = cl + xb;
+    if (r.n < total) break;
+    uint32_t len = (lb & 0xffffu) + ((b >> cl) & ((1u << xb) - 1u));
+    rd_drop(r, total);
+
+    rd_fill(r);
+    b = (uint32_t)r.bits;
+    e = dist[b & ((1u << F::DIST_BITS) - 1u)];
+    if (e & F::F_SUB) e = dist[F::sub_at(e) + ((b >> F::DIST_BITS) & ((1u << (e & 15u)) - 1u))];
+    if (!e) break;
+    cl    = e & 15u;
+    lb    = bt.v[32u + ((e >> 4) & 31u)];
+    xb    = lb >> 16;
+    total = cl + xb;
+    if (r.n < total) break;
+    uint32_t d = (lb & 0xffffu) + ((b >> cl) & ((1u << xb) - 1u));
+    rd_drop(r, total);
+    if (d > pos || len > cap - pos) break;         // d >= 1 always
+
+    if (pend_off != NONE) dst[pend_off] = (uint8_t)pend_val;
+    pend_off = NONE;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (d >= len) {
+      const uint8_t *sp = dst + (pos - d);
+      if ((uint32_t)lig < len) {
+        pend_val = sp[lig];
+        pend_off = pos + lig;
+      }
+      for (uint32_t k = lig + T; k < len; k += T) dst[pos + k] = sp[k];
+    } else {
+      coop_match<T>(dst, pos, d, len, lig);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    pos += len;
+  }
+  if (pend_off != NONE) dst[pend_off] = (uint8_t)pend_val;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  pos_io = pos;
+  return ok;
+}
+
+// Block loop (infl.c:1063-1092).  FAST selects the compact pass's symbol loop.
+template <int T, class F, class R, bool FAST>
+__device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
+                                          StreamLds<F> &L, const BaseTab *bt, int lig, int gshift,
+                                          uint64_t &fuel) {
   bool     fixed_ready = false;
   uint32_t bfinal = 0;
   while (!bfinal) {
@@ -642,7 +837,14 @@ __device__ __forceinline__ int block_loop(Reader &r, uint8_t *dst, uint32_t &pos
         fixed_ready = false;
         rc = setup_dynamic<T, F>(r, L, lig, gshift);
       }
-      if (rc == INFL_D_OK) rc = huffman_block<T, F>(r, dst, pos, cap, L, lig, fuel);
+      if (rc == INFL_D_OK) {
+        if constexpr (FAST) {
+          rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, *bt, lig) ? INFL_D_OK
+                                                                                   : INFL_D_NOFIT;
+        } else {
+          rc = huffman_block<T, F>(r, dst, pos, cap, L, lig, fuel);
+        }
+      }
     }
     if (rc != INFL_D_OK) return rc;
   }
@@ -654,29 +856,43 @@ __device__ __forceinline__ bool zlib_header_ok(const uint8_t *p) {   // infl.c:2
   return (cmf & 15u) == 8u && (cmf >> 4) <= 7u && ((cmf << 8) + flg) % 31u == 0 && !(flg & 0x20u);
 }
 
+__device__ __forceinline__ void rd_init(Reader &r, const uint8_t *src, uint32_t srclen, int, int) {
+  r.end = src + srclen;
+}
+template <int T>
+__device__ __forceinline__ void rd_init(FastReader<T> &r, const uint8_t *src, uint32_t srclen, int lig,
+                                        int gshift) {
+  r.src    = src;
+  r.ilen   = srclen;
+  r.ilen4  = srclen - 4;
+  r.lig    = lig;
+  r.gshift = gshift;
+}
+
 // Whole stream: the dispatcher of infl() for one contiguous input.
 // Returns the detail code.  `outlen` is what infl_output_pos() would report
 // after infl(); `pos` is the output position actually reached and `cur` the
 // first input byte with unread bits (both also valid when the stream stopped
 // early; the incremental API reports them).
-template <int T, class F>
+template <int T, class F, class R, bool FAST>
 __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srclen, uint8_t *dst,
-                                              uint32_t cap, bool zlib, StreamLds<F> &L, int lig,
-                                              int gshift, uint32_t &outlen, uint32_t &pos,
-                                              const uint8_t *&cur) {
+                                              uint32_t cap, bool zlib, StreamLds<F> &L,
+                                              const BaseTab *bt, int lig, int gshift,
+                                              uint32_t &outlen, uint32_t &pos, const uint8_t *&cur) {
   outlen = 0;
   pos    = 0;
   cur    = src;
   if (srclen == 0) return INFL_D_OK;               // infl.c:1547-1550
+  if (FAST && srclen < 8) return INFL_D_NOFIT;     // the fast reader needs a few bytes
 
   const uint8_t *p = src, *end = src + srclen;
-  uint64_t fuel = (uint64_t)srclen * 8u + 64u;     // every loop turn consumes >= 1 input bit
+  uint64_t fuel = (uint64_t)srclen * 8u + 64u;     // every block consumes >= 1 input bit
   bool     try_stored = true;                      // infl.c:1519-1531
   if (!zlib) try_stored = ((p[0] >> 1) & 3u) == 0;
   else if (srclen >= 3) try_stored = ((p[2] >> 1) & 3u) == 0;
 
-  Reader r;
-  r.end = end;
+  R r;
+  rd_init(r, src, srclen, lig, gshift);
   int rc;
 
   if (try_stored && !(zlib && srclen < 3)) {       // stored-only path, infl.c:206-267
@@ -714,7 +930,7 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
     p += 2;
   }
   rd_seek(r, p);
-  rc  = block_loop<T, F>(r, dst, pos, cap, L, lig, gshift, fuel);
+  rc  = block_loop<T, F, R, FAST>(r, dst, pos, cap, L, bt, lig, gshift, fuel);
   cur = rd_byte_ptr(r);
   if (rc == INFL_D_OK) outlen = pos;
   return rc;
@@ -737,14 +953,24 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
                                                         uint32_t *__restrict__ outlen,
                                                         int32_t *__restrict__ detail,
                                                         uint32_t *__restrict__ inpos) {
-  constexpr int G = 64 / T;                        // streams per wavefront
+  constexpr int  G    = 64 / T;                    // streams per wavefront
+  constexpr bool FAST = MODE == 1;
   __shared__ StreamLds<F> lds[G];
+  __shared__ BaseTab      bt;
 
   const int      lane   = threadIdx.x;
   const int      group  = lane / T;
   const int      lig    = lane % T;
   const int      gshift = group * T;
   const uint64_t i      = (uint64_t)blockIdx.x * G + group;
+
+  if (FAST) {                                      // all 64 lanes are still here
+    uint32_t base, xb;
+    if (lane < 32) length_base(lane < 29 ? lane : 0, base, xb);
+    else dist_base(lane - 32 < 30 ? lane - 32 : 0, base, xb);
+    bt.v[lane] = base | (xb << 16);
+    group_sync();
+  }
   if (i >= n) return;
   if (MODE == 2 && status[i] != INFL_STATUS_DEFERRED) return;
 
@@ -752,8 +978,15 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
   const uint64_t d0 = dst_off[i], d1 = dst_off[i + 1];
   uint32_t       out = 0, pos = 0;
   const uint8_t *cur = nullptr;
-  int rc = inflate_stream<T, F>(src + s0, (uint32_t)(s1 - s0), dst + d0, (uint32_t)(d1 - d0),
-                                (flags & 0xff) == 1, lds[group], lig, gshift, out, pos, cur);
+  int rc;
+  if constexpr (FAST)
+    rc = inflate_stream<T, F, FastReader<T>, true>(src + s0, (uint32_t)(s1 - s0), dst + d0,
+                                                (uint32_t)(d1 - d0), (flags & 0xff) == 1,
+                                                lds[group], &bt, lig, gshift, out, pos, cur);
+  else
+    rc = inflate_stream<T, F, Reader, false>(src + s0, (uint32_t)(s1 - s0), dst + d0,
+                                             (uint32_t)(d1 - d0), (flags & 0xff) == 1, lds[group],
+                                             nullptr, lig, gshift, out, pos, cur);
   if (lig == 0) {
     if (MODE == 1 && rc != INFL_D_OK) {
       status[i] = INFL_STATUS_DEFERRED;

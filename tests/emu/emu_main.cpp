@@ -15,6 +15,7 @@ struct Group {
   pthread_barrier_t     bar;
   std::atomic<uint64_t> mask{0};
 };
+int g_slots[64];   // ds_bpermute exchange buffer, one slot per lane of the wavefront
 thread_local dim3   t_threadIdx, t_blockIdx;
 thread_local Group *t_group = nullptr;
 thread_local int    t_lane  = 0;
@@ -30,6 +31,15 @@ uint64_t ballot(bool pred) {
   if (t_lane % g_lanes_per_group == 0) t_group->mask.store(0);
   group_barrier();
   return m;
+}
+
+// Every lane of the group publishes its value, then reads the addressed lane's.
+int bpermute(int byte_addr, int value) {
+  g_slots[t_lane] = value;
+  group_barrier();
+  int v = g_slots[(byte_addr >> 2) & 63];
+  group_barrier();
+  return v;
 }
 
 void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {

@@ -33,6 +33,7 @@ extern thread_local Group *t_group;
 extern thread_local int    t_lane;
 void     group_barrier();
 uint64_t ballot(bool pred);
+int      bpermute(int byte_addr, int value);
 void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 }  // namespace emu
 
@@ -46,6 +47,7 @@ void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 #define __builtin_amdgcn_wave_barrier() emu::group_barrier()
 #define __ballot(p) emu::ballot(p)
 #define __popcll(x) __builtin_popcountll(x)
+#define __builtin_amdgcn_ds_bpermute(a, v) emu::bpermute(a, v)
 
 static inline uint32_t __brev(uint32_t v) {
   v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
