@@ -105,23 +105,32 @@ struct RefFmt {
 // CompactFmt: 16-bit entries.  bits 0-3 code length (or subtable index bits),
 // bits 4-12 payload, bit 13 SUBTABLE, bit 14 BASE (length / distance symbol),
 // bit 15 LITERAL; END carries only its flag and a length, 0 = no code.
-// Length and distance bases are recomputed from the symbol index at decode.
+// A BASE entry stores its value as mantissa and shift, so decode needs no
+// second table: payload bits 0-3 = extra bits x, bits 4-6 = mantissa m, bit 7 =
+// "length 258"; length base = 3 + (m << x), distance base = 1 + (m << x).
 // ---------------------------------------------------------------------------
 struct CompactFmt {
   typedef uint16_t entry_t;
   static constexpr int LIT_BITS = 9, DIST_BITS = 7;
   static constexpr int LIT_CAP = 768, DIST_CAP = 320;
   static constexpr uint32_t F_LITERAL = 1u << 15, F_BASE = 1u << 14, F_SUB = 1u << 13, F_END = 1u << 12;
+  static constexpr uint32_t F_L258 = 1u << 11;
 
   static __device__ __forceinline__ entry_t lit_entry(uint32_t sym, uint32_t len) {
     if (sym < 256) return (entry_t)(F_LITERAL | (sym << 4) | len);
     if (sym == 256) return (entry_t)(F_END | len);
     if (sym > 285) return 0;
-    return (entry_t)(F_BASE | ((sym - 257) << 4) | len);
+    uint32_t i = sym - 257;
+    if (i == 28) return (entry_t)(F_BASE | F_L258 | len);
+    uint32_t x = i < 8 ? 0u : (i - 4) >> 2;
+    uint32_t m = i < 8 ? i : 4 + (i & 3);
+    return (entry_t)(F_BASE | (m << 8) | (x << 4) | len);
   }
   static __device__ __forceinline__ entry_t dist_entry(uint32_t sym, uint32_t len) {
     if (sym > 29) return 0;
-    return (entry_t)(F_BASE | (sym << 4) | len);
+    uint32_t x = sym < 4 ? 0u : (sym >> 1) - 1;
+    uint32_t m = sym < 4 ? sym : 2 + (sym & 1);
+    return (entry_t)(F_BASE | (m << 8) | (x << 4) | len);
   }
   // subtable offsets are even (main table and every subtable have even sizes): at / 2 fits 9 bits
   static __device__ __forceinline__ entry_t sub_entry(uint32_t at, uint32_t bits) {
@@ -130,6 +139,13 @@ struct CompactFmt {
   static __device__ __forceinline__ bool is_sub(uint32_t e) { return e & F_SUB; }
   static __device__ __forceinline__ uint32_t sub_at(uint32_t e) { return ((e >> 4) & 0x1ffu) << 1; }
   static __device__ __forceinline__ uint32_t sub_bits(uint32_t e) { return e & 15u; }
+  static __device__ __forceinline__ uint32_t xbits(uint32_t e) { return (e >> 4) & 15u; }
+  static __device__ __forceinline__ uint32_t len_base(uint32_t e) {
+    return (e & F_L258) ? 258u : 3u + (((e >> 8) & 7u) << xbits(e));
+  }
+  static __device__ __forceinline__ uint32_t dist_base(uint32_t e) {
+    return 1u + (((e >> 8) & 7u) << xbits(e));
+  }
   static __device__ __forceinline__ Sym lit_sym(uint32_t e) {
     Sym s;
     s.codelen = e & 15u;
@@ -138,8 +154,9 @@ struct CompactFmt {
     if (e & F_LITERAL) {
       s.kind = K_LITERAL;
     } else if (e & F_BASE) {
-      s.kind = K_BASE;
-      length_base(s.base & 31u, s.base, s.xbits);
+      s.kind  = K_BASE;
+      s.xbits = (e & F_L258) ? 0u : xbits(e);
+      s.base  = len_base(e);
     } else {
       s.kind = e ? K_END : K_INVALID;
     }
@@ -149,7 +166,8 @@ struct CompactFmt {
     Sym s;
     s.codelen = e & 15u;
     s.kind    = e ? K_BASE : K_INVALID;
-    dist_base((e >> 4) & 31u, s.base, s.xbits);
+    s.xbits   = xbits(e);
+    s.base    = dist_base(e);
     return s;
   }
 };
@@ -249,6 +267,11 @@ __device__ __forceinline__ const uint8_t *rd_byte_ptr(const Reader &r) { return 
 // shifted into place when used, so the tail needs no byte loop and nothing
 // past the stream's last byte is ever read.  Needs ilen >= 4; shorter streams
 // are left to the other reader.
+// Unlike the reference's reservoir this reader keeps handing out zero words
+// after the last input byte and counts them in `n`; rd_overrun() tells whether
+// any such bit has been consumed.  The compact pass checks it before a stored
+// copy and once at the end of the stream, and gives the stream to the second
+// pass if it is set: that pass rejects the stream exactly as the reference does.
 template <int T>
 struct FastReader {
   const uint8_t *src;
@@ -291,18 +314,15 @@ __device__ __forceinline__ void rd_seek(FastReader<T> &r, const uint8_t *p) {
 template <int T>
 __device__ __forceinline__ void rd_fill(FastReader<T> &r) {
   if (r.n < 32) {
-    uint32_t k = r.ilen - r.ipos;
-    k = k < 4 ? k : 4;
     uint32_t idx = (r.ipos - r.wbase) >> 2;          // word of the window, group-uniform
     if (idx >= (uint32_t)T) {
       rd_promote(r);
       idx -= T;
     }
     uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r.gshift + idx) << 2), (int)r.cur);
-    w = k ? w : 0u;                                  // nothing left: keep the bits above n zero
-    r.bits |= (uint64_t)w << r.n;
-    r.n    += k * 8;
-    r.ipos += k;
+    r.bits |= (uint64_t)w << r.n;                    // words past the end of the stream are zero
+    r.n    += 32;
+    r.ipos += 4;
   }
 }
 
@@ -318,6 +338,12 @@ __device__ __forceinline__ const uint8_t *rd_byte_ptr(const FastReader<T> &r) {
 }
 template <int T>
 __device__ __forceinline__ const uint8_t *rd_end(const FastReader<T> &r) { return r.src + r.ilen; }
+// true once bits past the end of the stream have been consumed (see the reader's comment)
+template <int T>
+__device__ __forceinline__ bool rd_overrun(const FastReader<T> &r) {
+  return (uint64_t)r.ipos * 8u - r.n > (uint64_t)r.ilen * 8u;
+}
+__device__ __forceinline__ bool rd_overrun(const Reader &) { return false; }
 __device__ __forceinline__ const uint8_t *rd_end(const Reader &r) { return r.end; }
 
 template <class F>
@@ -661,6 +687,7 @@ __device__ __forceinline__ int stored_block(R &r, uint8_t *dst, uint32_t &pos, u
   rd_drop(r, 32);
   if (len != (nlen ^ 0xffffu)) return INFL_D_INVALID;
   if (len > cap - pos) return INFL_D_FULL;
+  if (rd_overrun(r)) return INFL_D_NEED_INPUT;
   const uint8_t *s = rd_byte_ptr(r);
   if ((size_t)(rd_end(r) - s) < len) return INFL_D_NEED_INPUT;
   coop_copy<T>(dst + pos, s, len, lig);
@@ -719,21 +746,19 @@ __device__ __forceinline__ int huffman_block(R &r, uint8_t *dst, uint32_t &pos_i
   return rc;
 }
 
-// Length / distance base values shared by all streams of a workgroup (compact
-// pass): entry = base | extra bits << 16; [0..31] lengths (index = symbol - 257),
-// [32..63] distances.  Saves recomputing them per match.
-struct BaseTab {
-  uint32_t v[64];
-};
-
 // Symbol loop of the compact pass.  Same acceptance as huffman_block(); a stream
 // that stops for any reason is decoded again by the second pass, so the reason
 // is not reported.
+//
+// Input accounting is relaxed inside this loop: the reader hands out zero bits
+// past the end of the stream and counts them as if they were there, and the
+// caller checks once, when the stream is finished, that no bit past the end was
+// consumed (a stream that needs such bits is rejected by the reference, so it
+// goes to the second pass).  Output bounds are checked per symbol.
 template <int T>
 __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t *dst, uint32_t &pos_io,
                                                       uint32_t cap, const uint16_t *lit,
-                                                      const uint16_t *dist, const BaseTab &bt,
-                                                      int lig) {
+                                                      const uint16_t *dist, int lig) {
   typedef CompactFmt F;
   constexpr uint32_t NONE = 0xffffffffu;
   uint32_t pos = pos_io;
@@ -750,39 +775,32 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
     if (e & F::F_SUB) e = lit[F::sub_at(e) + ((b >> F::LIT_BITS) & ((1u << (e & 15u)) - 1u))];
     uint32_t cl = e & 15u;
     if (e & F::F_LITERAL) {
-      if (r.n < cl || pos >= cap) break;
+      if (pos >= cap) break;
       rd_drop(r, cl);
       if (lig == 0) dst[pos] = (uint8_t)(e >> 4);
       pos++;
       continue;
     }
     if (!(e & F::F_BASE)) {                        // end of block, or no code
-      if (e && r.n >= cl) {
+      if (e) {
         rd_drop(r, cl);
         ok = true;
       }
       break;
     }
-    uint32_t lb    = bt.v[(e >> 4) & 31u];
-    uint32_t xb    = lb >> 16;
-    uint32_t total = cl + xb;
-    if (r.n < total) break;
-    uint32_t len = (lb & 0xffffu) + ((b >> cl) & ((1u << xb) - 1u));
-    rd_drop(r, total);
+    uint32_t xb  = (e & F::F_L258) ? 0u : F::xbits(e);
+    uint32_t len = F::len_base(e) + ((b >> cl) & ((1u << xb) - 1u));
+    rd_drop(r, cl + xb);
 
     rd_fill(r);
     b = (uint32_t)r.bits;
     e = dist[b & ((1u << F::DIST_BITS) - 1u)];
     if (e & F::F_SUB) e = dist[F::sub_at(e) + ((b >> F::DIST_BITS) & ((1u << (e & 15u)) - 1u))];
-    if (!e) break;
-    cl    = e & 15u;
-    lb    = bt.v[32u + ((e >> 4) & 31u)];
-    xb    = lb >> 16;
-    total = cl + xb;
-    if (r.n < total) break;
-    uint32_t d = (lb & 0xffffu) + ((b >> cl) & ((1u << xb) - 1u));
-    rd_drop(r, total);
-    if (d > pos || len > cap - pos) break;         // d >= 1 always
+    cl = e & 15u;
+    xb = F::xbits(e);
+    uint32_t d = F::dist_base(e) + ((b >> cl) & ((1u << xb) - 1u));
+    rd_drop(r, cl + xb);
+    if (!e || d > pos || len > cap - pos) break;   // d >= 1 for every real entry
 
     if (pend_off != NONE) dst[pend_off] = (uint8_t)pend_val;
     pend_off = NONE;
@@ -809,8 +827,7 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
 // Block loop (infl.c:1063-1092).  FAST selects the compact pass's symbol loop.
 template <int T, class F, class R, bool FAST>
 __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
-                                          StreamLds<F> &L, const BaseTab *bt, int lig, int gshift,
-                                          uint64_t &fuel) {
+                                          StreamLds<F> &L, int lig, int gshift, uint64_t &fuel) {
   bool     fixed_ready = false;
   uint32_t bfinal = 0;
   while (!bfinal) {
@@ -839,7 +856,7 @@ __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uin
       }
       if (rc == INFL_D_OK) {
         if constexpr (FAST) {
-          rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, *bt, lig) ? INFL_D_OK
+          rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, lig) ? INFL_D_OK
                                                                                    : INFL_D_NOFIT;
         } else {
           rc = huffman_block<T, F>(r, dst, pos, cap, L, lig, fuel);
@@ -877,7 +894,7 @@ __device__ __forceinline__ void rd_init(FastReader<T> &r, const uint8_t *src, ui
 template <int T, class F, class R, bool FAST>
 __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srclen, uint8_t *dst,
                                               uint32_t cap, bool zlib, StreamLds<F> &L,
-                                              const BaseTab *bt, int lig, int gshift,
+                                              int lig, int gshift,
                                               uint32_t &outlen, uint32_t &pos, const uint8_t *&cur) {
   outlen = 0;
   pos    = 0;
@@ -930,7 +947,8 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
     p += 2;
   }
   rd_seek(r, p);
-  rc  = block_loop<T, F, R, FAST>(r, dst, pos, cap, L, bt, lig, gshift, fuel);
+  rc  = block_loop<T, F, R, FAST>(r, dst, pos, cap, L, lig, gshift, fuel);
+  if (rc == INFL_D_OK && rd_overrun(r)) rc = INFL_D_NEED_INPUT;
   cur = rd_byte_ptr(r);
   if (rc == INFL_D_OK) outlen = pos;
   return rc;
@@ -956,7 +974,6 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
   constexpr int  G    = 64 / T;                    // streams per wavefront
   constexpr bool FAST = MODE == 1;
   __shared__ StreamLds<F> lds[G];
-  __shared__ BaseTab      bt;
 
   const int      lane   = threadIdx.x;
   const int      group  = lane / T;
@@ -964,13 +981,6 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
   const int      gshift = group * T;
   const uint64_t i      = (uint64_t)blockIdx.x * G + group;
 
-  if (FAST) {                                      // all 64 lanes are still here
-    uint32_t base, xb;
-    if (lane < 32) length_base(lane < 29 ? lane : 0, base, xb);
-    else dist_base(lane - 32 < 30 ? lane - 32 : 0, base, xb);
-    bt.v[lane] = base | (xb << 16);
-    group_sync();
-  }
   if (i >= n) return;
   if (MODE == 2 && status[i] != INFL_STATUS_DEFERRED) return;
 
@@ -982,11 +992,11 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
   if constexpr (FAST)
     rc = inflate_stream<T, F, FastReader<T>, true>(src + s0, (uint32_t)(s1 - s0), dst + d0,
                                                 (uint32_t)(d1 - d0), (flags & 0xff) == 1,
-                                                lds[group], &bt, lig, gshift, out, pos, cur);
+                                                lds[group], lig, gshift, out, pos, cur);
   else
     rc = inflate_stream<T, F, Reader, false>(src + s0, (uint32_t)(s1 - s0), dst + d0,
                                              (uint32_t)(d1 - d0), (flags & 0xff) == 1, lds[group],
-                                             nullptr, lig, gshift, out, pos, cur);
+                                             lig, gshift, out, pos, cur);
   if (lig == 0) {
     if (MODE == 1 && rc != INFL_D_OK) {
       status[i] = INFL_STATUS_DEFERRED;
