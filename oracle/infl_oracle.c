@@ -297,6 +297,13 @@ stored_in_stream(rd_t *r, uint8_t *dst, size_t *dpos, size_t cap) {
   return ORACLE_D_OK;
 }
 
+/* optional observer of matches (statistics only) */
+static void (*g_match_hook)(unsigned pos, unsigned len, unsigned dist);
+void
+oracle_set_match_hook(void (*hook)(unsigned, unsigned, unsigned)) {
+  g_match_hook = hook;
+}
+
 /* optional observer of dynamic headers (statistics for table sizing experiments) */
 static void (*g_header_hook)(const uint8_t *lens, unsigned hlit, unsigned hdist);
 
@@ -383,6 +390,63 @@ static int
 huffman_block(rd_t *r, uint8_t *dst, size_t *dpos, size_t cap, const tabs_t *t) {
   size_t pos = *dpos;
 
+  /* Fast loop for the bulk of a block: at least 16 input bytes and 258 + 40 output bytes are
+     left, so a symbol can neither run out of input nor overflow the output, and copies may
+     write whole 8-byte words past the end of a match (inside the capacity), as the
+     reference's own copy kernels do (infl.c:353-376).  Same decisions as the careful loop
+     below, which finishes the block. */
+  while ((size_t)(r->end - r->p) >= 16 && cap - pos >= 258 + 40) {
+    uint32_t e;
+    unsigned total, len, dist;
+    uint64_t w;
+
+    if (r->n < 48) {                               /* >= 48 bits cover literal/length + distance */
+      unsigned k = (64u - r->n) >> 3;
+      memcpy(&w, r->p, 8);
+      if (k < 8) w &= ((uint64_t)1 << (k * 8)) - 1u;
+      r->bits |= w << r->n;
+      r->p    += k;
+      r->n    += k * 8;
+    }
+    e = tab_lookup(t->lit, LIT_BITS, r->bits);
+    if (!e) return ORACLE_D_INVALID;
+    total = E_TOTAL(e);
+    if (e & E_LITERAL) {
+      rd_drop(r, total);
+      dst[pos++] = (uint8_t)E_BASE(e);
+      e = tab_lookup(t->lit, LIT_BITS, r->bits);   /* one literal of run-ahead */
+      if ((e & E_LITERAL) && r->n >= 32) {
+        rd_drop(r, E_TOTAL(e));
+        dst[pos++] = (uint8_t)E_BASE(e);
+      }
+      continue;
+    }
+    if (e & E_END) {
+      rd_drop(r, total);
+      *dpos = pos;
+      return ORACLE_D_OK;
+    }
+    len = E_BASE(e) + (unsigned)((r->bits & (((uint64_t)1 << total) - 1u)) >> E_CODELEN(e));
+    rd_drop(r, total);
+    e = tab_lookup(t->dist, DIST_BITS, r->bits);
+    if (!e) return ORACLE_D_INVALID;
+    total = E_TOTAL(e);
+    dist = E_BASE(e) + (unsigned)((r->bits & (((uint64_t)1 << total) - 1u)) >> E_CODELEN(e));
+    rd_drop(r, total);
+    if (!dist || (size_t)dist > pos) return ORACLE_D_INVALID;
+    if (dist >= 8) {
+      const uint8_t *sp = dst + pos - dist;
+      uint8_t *dp = dst + pos, *de = dp + len;
+      do { memcpy(&w, sp, 8); memcpy(dp, &w, 8); sp += 8; dp += 8; } while (dp < de);
+    } else if (dist == 1) {
+      memset(dst + pos, dst[pos - 1], len);
+    } else {
+      const uint8_t *sp = dst + pos - dist;
+      for (unsigned i = 0; i < len; i++) dst[pos + i] = sp[i];
+    }
+    pos += len;
+  }
+
   for (;;) {
     uint32_t e;
     unsigned total, len, dist;
@@ -417,6 +481,7 @@ huffman_block(rd_t *r, uint8_t *dst, size_t *dpos, size_t cap, const tabs_t *t) 
 
     if (!dist || (size_t)dist > pos) return ORACLE_D_INVALID;
     if (len > cap - pos)             return ORACLE_D_FULL;
+    if (g_match_hook) g_match_hook((unsigned)pos, len, dist);
 
     if (dist >= len) {
       memcpy(dst + pos, dst + pos - dist, len);

@@ -41,6 +41,9 @@ int oracle_infl_batch(const uint8_t *src, const uint64_t *src_off, uint8_t *dst,
                       const uint64_t *dst_off, int flags, size_t n, int32_t *status,
                       uint32_t *outlen, int nthreads);
 
+/* observer called for every match decoded (NULL = off) */
+void oracle_set_match_hook(void (*hook)(unsigned pos, unsigned len, unsigned dist));
+
 /* observer called with the code lengths of every dynamic block header decoded (NULL = off) */
 void oracle_set_header_hook(void (*hook)(const uint8_t *lens, unsigned hlit, unsigned hdist));
 

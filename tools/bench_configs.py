@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Secondary measurements on one GPU (not the headline): the parity-test configurations of the
+build's measurement plan, each decoded from device-resident arenas and checked against the CPU
+oracle before a number is printed.
+
+  stored   65 536 x 64 KiB incompressible payload as stored blocks + zlib wrapper (copy ceiling)
+  fixed    the text workload compressed with Z_FIXED (fixed-Huffman blocks only)
+  png      4 096 PNG-like images (128x128 RGBA scanlines, zlib-6) fed as IDAT pieces with
+           infl_include() and decoded with one infl_many() call (host path, PCIe inclusive)
+  mixed    text streams with log-uniform sizes 1 KiB .. 256 KiB, sorted by size (config 5 shape)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import workloads as wl  # noqa: E402
+
+
+def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5):
+    import torch
+    dev = torch.device("cuda", 0)
+    n = len(comps) * tile
+    lens = np.tile(np.array([len(c) for c in comps], dtype=np.uint64), tile)
+    caps = np.tile(np.array(raws_len, dtype=np.uint64), tile)
+    src_off = np.zeros(n + 1, dtype=np.uint64)
+    dst_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=src_off[1:])
+    np.cumsum(caps, out=dst_off[1:])
+    pool = torch.from_numpy(np.frombuffer(b"".join(comps), dtype=np.uint8).copy()).to(dev)
+    d_src = torch.cat([pool.repeat(tile), torch.zeros(64, dtype=torch.uint8, device=dev)])
+    d_dst = torch.empty(int(dst_off[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_so = torch.from_numpy(src_off.view(np.int64)).to(dev)
+    d_do = torch.from_numpy(dst_off.view(np.int64)).to(dev)
+    d_st = torch.full((n,), -99, dtype=torch.int32, device=dev)
+    d_ol = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def step():
+        assert eng.lib.infl_batch_dev(d_src.data_ptr(), d_so.data_ptr(), d_dst.data_ptr(), d_do.data_ptr(), flags, n,
+                                      d_st.data_ptr(), d_ol.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    step()
+    torch.cuda.synchronize()
+    assert bool((d_st == 0).all())
+    k = min(len(comps), 128)
+    s, so, do = wl.pack(comps[:k], raws_len[:k])
+    want, _, wol = oracle.infl_batch(s, so, do, flags, 8)
+    got = d_dst[: int(do[-1])].cpu().numpy()
+    assert np.array_equal(got, want[: int(do[-1])]), "differs from the oracle"
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record(); step(); b.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    out_b, in_b = int(dst_off[-1]), int(src_off[-1])
+    return {"streams": n, "out_bytes": out_b, "in_bytes": in_b, "kernel_ms": round(ms, 3),
+            "decompressed_MB_per_s": round(out_b / ms / 1e3, 1),
+            "algorithmic_GB_per_s": round((out_b + in_b) / ms / 1e6, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="stored,fixed,mixed,png")
+    ap.add_argument("--scale", type=float, default=1.0)
+    args = ap.parse_args()
+    import torch  # noqa: F401  (same HIP runtime for the engine)
+    from defl_amd import capi
+    from tests import oracle_lib
+    eng, oracle = capi.load(), oracle_lib.load()
+    assert eng.lib.infl_gpu_init(0) == 0
+    which = args.which.split(",")
+    if "stored" in which:
+        pairs = [wl.stored_stream(i, 65536) for i in range(256)]
+        r = run_device(eng, oracle, [p[1] for p in pairs], [65536] * 256, 1, 5, int(256 * args.scale))
+        print(json.dumps({"config": "stored-only 64 KiB streams", **r}), flush=True)
+    if "fixed" in which:
+        raws = [wl.text_stream(i) for i in range(256)]
+        comps = [wl.deflate(x, 6, True, zlib.Z_FIXED) for x in raws]
+        r = run_device(eng, oracle, comps, [65536] * 256, 1, 5, int(256 * args.scale))
+        print(json.dumps({"config": "fixed-Huffman-only 64 KiB text streams", **r}), flush=True)
+    if "mixed" in which:
+        rng = np.random.default_rng(5)
+        sizes = np.sort(np.exp(rng.uniform(np.log(1024), np.log(262144), 512)).astype(int))[::-1]
+        raws = [wl.text_stream(1000 + i, int(sz)) for i, sz in enumerate(sizes)]
+        comps = [wl.deflate(x) for x in raws]
+        r = run_device(eng, oracle, comps, [len(x) for x in raws], 1, 5, int(64 * args.scale))
+        print(json.dumps({"config": "mixed sizes 1 KiB..256 KiB (log-uniform), sorted descending", **r}), flush=True)
+    if "png" in which:
+        n = int(4096 * args.scale)
+        raws = [wl.png_like(i % 256) for i in range(n)]
+        comps = {i: wl.deflate(raws[i]) for i in range(min(n, 256))}
+        lib = eng.lib
+        outs = [(C.c_uint8 * len(raws[i]))() for i in range(n)]
+        sts = (C.c_void_p * n)()
+        keep, npieces = [], 0
+        t0 = time.perf_counter()
+        for i in range(n):
+            sts[i] = lib.infl_init(outs[i], len(raws[i]), 1)
+            for piece in wl.idat_pieces(i % 256, comps[i % 256]):
+                buf = (C.c_uint8 * len(piece)).from_buffer_copy(piece)
+                keep.append(buf)
+                lib.infl_include(sts[i], buf, len(piece))
+                npieces += 1
+        t_inc = time.perf_counter() - t0
+        status = (C.c_int32 * n)()
+        lib.infl_many(sts, n, status)            # warm-up (workspace allocation)
+        t0 = time.perf_counter()
+        assert lib.infl_many(sts, n, status) == 0
+        t_many = time.perf_counter() - t0
+        assert all(s == 0 for s in status)
+        for i in range(0, n, 97):
+            assert bytes(outs[i]) == raws[i]
+        out_b = sum(len(x) for x in raws)
+        for i in range(n):
+            lib.infl_destroy(sts[i])
+        print(json.dumps({"config": "PNG IDAT: %d images, infl_include per piece + one infl_many (host memory, "
+                                    "PCIe and gather included)" % n, "streams": n, "pieces_per_image": round(npieces / n, 1),
+                          "out_bytes": out_b, "infl_many_ms": round(t_many * 1e3, 2),
+                          "decompressed_MB_per_s": round(out_b / t_many / 1e6, 1),
+                          "include_calls_ms": round(t_inc * 1e3, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
