@@ -130,7 +130,7 @@ int infl_gpu_set_lanes_per_stream(int lanes) {
 }
 
 int infl_gpu_set_table_variant(int variant) {
-  if (variant == 0 || variant == 1) g_variant = variant;
+  if (variant >= 0 && variant <= 2) g_variant = variant;
   return g_variant;
 }
 

@@ -423,7 +423,7 @@ __device__ __noinline__ int build_table(typename F::entry_t *table, const uint8_
   const int      ref_bits  = litlen ? REF_LIT_BITS : REF_DIST_BITS;
   const uint32_t ref_cap   = litlen ? REF_LIT_CAP : REF_DIST_CAP;
   const uint32_t main_size = 1u << mainbits;
-  const uint64_t gmask     = (T == 64) ? ~0ull : (((1ull << T) - 1ull) << gshift);
+  const uint64_t gmask     = (T == 64) ? ~0ull : (((1ull << (T & 63)) - 1ull) << gshift);
 
   group_sync();
   for (int i = lig; i < 16; i += T) L.count[i] = 0;
@@ -824,10 +824,260 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
   return ok;
 }
 
-// Block loop (infl.c:1063-1092).  FAST selects the compact pass's symbol loop.
-template <int T, class F, class R, bool FAST>
+// ---------------------------------------------------------------------------
+// Parallel symbol decode of one Huffman block by a whole wavefront (T = 64).
+//
+// The serial loops above advance one symbol per stream per pass over the
+// instruction stream, so a stream never goes faster than one dependency chain
+// allows.  Here the 64 lanes decode 64 consecutive sub-sequences of PAR_S bits
+// of the SAME block at once:
+//   1. scan      every lane decodes from its (guessed) start to the end of its
+//                sub-sequence and notes where it left it, how many bytes it
+//                would produce and whether it met the end-of-block code;
+//   2. fix up    a lane whose predecessor left at another bit position than the
+//                lane started from rescans from there; repeated until nothing
+//                changes.  DEFLATE symbol chains re-synchronise after ~10
+//                symbols, so this takes two or three rounds;
+//   3. place     a prefix sum of the byte counts gives every lane its output
+//                offset; as many lanes as fit the PAR_R-byte round buffer take
+//                part;
+//   4. emit      every lane walks its chain once more and writes one 16-bit
+//                "link" per output byte into LDS: a literal value, an index of
+//                an earlier byte of this round, or how far before the round the
+//                byte comes from (already final in global memory);
+//   5. resolve   bytes from before the round are fetched, then pointer jumping
+//                turns every link into a value (log2(chain depth) sweeps), and
+//                the round is written out with coalesced stores.
+// The next round starts where the last participating lane stopped.  Anything
+// unusual (malformed data on the true chain, output capacity, oversized lanes)
+// returns false and the stream is decoded again by the serial second pass, so
+// this function only has to be right when it succeeds.
+// ---------------------------------------------------------------------------
+constexpr int      PAR_S        = 256;               // sub-sequence length in bits
+constexpr int      PAR_R        = 6144;              // output bytes per round (LDS links)
+constexpr int      PAR_IN       = 2 * PAR_S + 6;     // staged input words: 64 * PAR_S bits + slack
+constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane stops scanning beyond this many bytes
+constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
+
+struct ParLds {
+  uint32_t in[PAR_IN];
+  uint16_t link[PAR_R];
+};
+static_assert(PAR_LANE_CAP + 258 <= PAR_R, "lane 0 always fits a round");
+
+struct ParCtx {
+  const uint32_t *in;
+  uint32_t        inbase;        // bit position of in[0]
+  uint32_t        total_bits;    // stream length in bits
+  const uint16_t *lit, *dist;
+};
+
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
+}
+
+__device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t p) {
+  uint32_t rel = p - c.inbase, w = rel >> 5;
+  uint64_t v = ((uint64_t)c.in[w + 1] << 32) | c.in[w];
+  return (uint32_t)(v >> (rel & 31u));
+}
+
+// One symbol at bit position p.  Returns 0 = none / malformed, 1 = literal (val = byte),
+// 2 = end of block, 3 = match (len, val = distance); pnext = position of the next symbol.
+__device__ __forceinline__ uint32_t par_step(const ParCtx &c, uint32_t p, uint32_t &pnext,
+                                             uint32_t &len, uint32_t &val) {
+  typedef CompactFmt F;
+  uint32_t b = par_peek(c, p);
+  uint32_t e = c.lit[b & ((1u << F::LIT_BITS) - 1u)];
+  if (e & F::F_SUB) e = c.lit[F::sub_at(e) + ((b >> F::LIT_BITS) & ((1u << (e & 15u)) - 1u))];
+  uint32_t cl = e & 15u, kind;
+  if (e & F::F_LITERAL) {
+    pnext = p + cl;
+    len   = 1;
+    val   = (e >> 4) & 0xffu;
+    kind  = 1;
+  } else if (!(e & F::F_BASE)) {
+    pnext = p + cl;
+    len   = 0;
+    val   = 0;
+    kind  = e ? 2u : 0u;
+  } else {
+    uint32_t xb = (e & F::F_L258) ? 0u : F::xbits(e);
+    len = F::len_base(e) + ((b >> cl) & ((1u << xb) - 1u));
+    uint32_t q = p + cl + xb;
+    b = par_peek(c, q);
+    e = c.dist[b & ((1u << F::DIST_BITS) - 1u)];
+    if (e & F::F_SUB) e = c.dist[F::sub_at(e) + ((b >> F::DIST_BITS) & ((1u << (e & 15u)) - 1u))];
+    cl    = e & 15u;
+    xb    = F::xbits(e);
+    val   = F::dist_base(e) + ((b >> cl) & ((1u << xb) - 1u));
+    pnext = q + cl + xb;
+    kind  = e ? 3u : 0u;
+  }
+  if (pnext > c.total_bits) kind = 0;                // would need bits past the end of the stream
+  return kind;
+}
+
+// stop: 0 = left the sub-sequence (or hit the byte cap), 1 = end of block, 2 = malformed
+__device__ __forceinline__ void par_scan(const ParCtx &c, uint32_t start, uint32_t limit,
+                                         uint32_t &exit, uint32_t &nout, uint32_t &stop) {
+  uint32_t p = start, o = 0, st = 0;
+  while (p < limit && !st && o < PAR_LANE_CAP) {
+    uint32_t pn, len, val;
+    uint32_t kind = par_step(c, p, pn, len, val);
+    if (kind == 0) {
+      st = 2;
+    } else {
+      p = pn;
+      if (kind == 2) st = 1;
+      else o += len;
+    }
+  }
+  exit = p;
+  nout = o;
+  stop = st;
+}
+
+__device__ __noinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
+                                                    uint32_t cap, const uint16_t *lit,
+                                                    const uint16_t *dist, ParLds &P, int lane) {
+  uint32_t       pos        = pos_io;
+  uint32_t       B          = r.ipos * 8u - r.n;     // bit position of the block's first symbol
+  const uint32_t total_bits = r.ilen * 8u;
+  uint32_t       guard      = total_bits + 8u;       // every round consumes at least one bit
+  bool           done       = false;
+
+  while (!done) {
+    if (guard-- == 0) return false;
+
+    // stage the input of this round (coalesced, clamped inside the stream, zero padded)
+    const uint32_t inbyte = (B >> 3) & ~3u;
+    group_sync();
+    for (uint32_t w = lane; w < (uint32_t)PAR_IN; w += 64) {
+      uint32_t off = inbyte + 4u * w;
+      uint32_t q   = off < r.ilen4 ? off : r.ilen4;
+      uint32_t raw;
+      __builtin_memcpy(&raw, r.src + q, 4);
+      uint32_t d = off - q;
+      P.in[w] = d >= 4 ? 0u : raw >> (8u * d);
+    }
+    group_sync();
+    ParCtx c;
+    c.in         = P.in;
+    c.inbase     = inbyte * 8u;
+    c.total_bits = total_bits;
+    c.lit        = lit;
+    c.dist       = dist;
+
+    // 1. scan, 2. fix up
+    const uint32_t limit = B + (uint32_t)(lane + 1) * PAR_S;
+    uint32_t       start = B + (uint32_t)lane * PAR_S, exit, nout, stop;
+    par_scan(c, start, limit, exit, nout, stop);
+    for (int iter = 0; iter < 64; iter++) {
+      uint32_t pe       = wave_read(exit, lane ? lane - 1 : 0);
+      uint64_t stopmask = __ballot(stop != 0);
+      bool     dead     = (stopmask & ((1ull << lane) - 1ull)) != 0;   // behind the end of the block
+      bool     changed  = lane > 0 && !dead && pe != start;
+      if (!__ballot(changed)) break;
+      if (changed) {
+        start = pe;
+        par_scan(c, start, limit, exit, nout, stop);
+      }
+    }
+
+    // 3. place
+    const uint64_t stopmask   = __ballot(stop != 0);
+    const uint32_t first_stop = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : 64u;
+    if (first_stop < 64 && wave_read(stop, first_stop) == 2) return false;   // malformed on the true chain
+    const bool active = (uint32_t)lane <= first_stop;
+    uint32_t   cum    = active ? nout : 0;
+    for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+      uint32_t t = wave_read(cum, (uint32_t)lane >= dlt ? lane - dlt : 0);
+      if ((uint32_t)lane >= dlt) cum += t;
+    }
+    const uint32_t m = (uint32_t)__popcll(__ballot(active && cum <= (uint32_t)PAR_R));
+    if (m == 0) return false;
+    const uint32_t total_out = wave_read(cum, m - 1);
+    if (total_out > cap - pos) return false;
+
+    // 4. emit links
+    bool bad = false;
+    if ((uint32_t)lane < m) {
+      uint32_t p = start, o = cum - nout;
+      while (p < exit) {
+        uint32_t pn, len, val;
+        uint32_t kind = par_step(c, p, pn, len, val);
+        if (kind == 1) {
+          P.link[o] = (uint16_t)(LK_LIT | val);
+          o++;
+        } else if (kind == 3) {
+          if (val > pos + o) {                       // distance reaches before the output start
+            bad = true;
+            break;
+          }
+          for (uint32_t k = 0; k < len; k++) {
+            uint32_t i = o + k;
+            P.link[i] = (uint16_t)(val > i ? LK_EXT | (val - i - 1u) : i - val);
+          }
+          o += len;
+        } else {
+          break;                                     // end of block (malformed cannot happen here)
+        }
+        p = pn;
+      }
+    }
+    if (__ballot(bad)) return false;
+    group_sync();
+
+    // 5. resolve: bytes from before this round, then pointer jumping, then write out
+    for (uint32_t i = lane; i < total_out; i += 64) {
+      uint32_t v = P.link[i];
+      if (v & LK_EXT) P.link[i] = (uint16_t)(LK_LIT | dst[pos - 1u - (v & 0x7fffu)]);
+    }
+    group_sync();
+    for (int it = 0; it < 16; it++) {
+      bool more = false;
+      for (uint32_t i = lane; i < total_out; i += 64) {
+        uint32_t v = P.link[i];
+        if (!(v & LK_LIT)) {
+          uint32_t u = P.link[v];
+          P.link[i] = (uint16_t)u;
+          more |= !(u & LK_LIT);
+        }
+      }
+      group_sync();
+      if (!__ballot(more)) break;
+    }
+    for (uint32_t i = (uint32_t)lane * 4u; i < total_out; i += 256) {
+      if (i + 4 <= total_out) {
+        uint64_t q;
+        __builtin_memcpy(&q, &P.link[i], 8);
+        uint32_t w = (uint32_t)(q & 0xffu) | ((uint32_t)(q >> 8) & 0xff00u) |
+                     ((uint32_t)(q >> 16) & 0xff0000u) | ((uint32_t)(q >> 24) & 0xff000000u);
+        __builtin_memcpy(dst + pos + i, &w, 4);
+      } else {
+        for (uint32_t k = i; k < total_out; k++) dst[pos + k] = (uint8_t)P.link[k];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    pos += total_out;
+    B    = wave_read(exit, m - 1);
+    done = first_stop < m;                           // the end-of-block code has been consumed
+  }
+  pos_io = pos;
+  rd_seek(r, r.src + (B >> 3));                      // put the serial reader behind the block
+  rd_fill(r);
+  rd_drop(r, B & 7u);
+  return true;
+}
+
+// Block loop (infl.c:1063-1092).  SYM selects the symbol loop: 0 = huffman_block (any table
+// format, exact failure reasons), 1 = huffman_block_compact, 2 = huffman_block_parallel.
+template <int T, class F, class R, int SYM>
 __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
-                                          StreamLds<F> &L, int lig, int gshift, uint64_t &fuel) {
+                                          StreamLds<F> &L, ParLds *par, int lig, int gshift,
+                                          uint64_t &fuel) {
   bool     fixed_ready = false;
   uint32_t bfinal = 0;
   while (!bfinal) {
@@ -855,7 +1105,10 @@ __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uin
         rc = setup_dynamic<T, F>(r, L, lig, gshift);
       }
       if (rc == INFL_D_OK) {
-        if constexpr (FAST) {
+        if constexpr (SYM == 2) {
+          rc = huffman_block_parallel(r, dst, pos, cap, L.lit, L.dist, *par, lig) ? INFL_D_OK
+                                                                                   : INFL_D_NOFIT;
+        } else if constexpr (SYM == 1) {
           rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, lig) ? INFL_D_OK
                                                                                    : INFL_D_NOFIT;
         } else {
@@ -891,16 +1144,17 @@ __device__ __forceinline__ void rd_init(FastReader<T> &r, const uint8_t *src, ui
 // after infl(); `pos` is the output position actually reached and `cur` the
 // first input byte with unread bits (both also valid when the stream stopped
 // early; the incremental API reports them).
-template <int T, class F, class R, bool FAST>
+template <int T, class F, class R, int SYM>
 __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srclen, uint8_t *dst,
                                               uint32_t cap, bool zlib, StreamLds<F> &L,
-                                              int lig, int gshift,
+                                              ParLds *par, int lig, int gshift,
                                               uint32_t &outlen, uint32_t &pos, const uint8_t *&cur) {
   outlen = 0;
   pos    = 0;
   cur    = src;
   if (srclen == 0) return INFL_D_OK;               // infl.c:1547-1550
-  if (FAST && srclen < 8) return INFL_D_NOFIT;     // the fast reader needs a few bytes
+  if (SYM != 0 && srclen < 8) return INFL_D_NOFIT; // the fast reader needs a few bytes
+  if (SYM == 2 && srclen >= (1u << 28)) return INFL_D_NOFIT;   // 32-bit bit positions
 
   const uint8_t *p = src, *end = src + srclen;
   uint64_t fuel = (uint64_t)srclen * 8u + 64u;     // every block consumes >= 1 input bit
@@ -947,7 +1201,7 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
     p += 2;
   }
   rd_seek(r, p);
-  rc  = block_loop<T, F, R, FAST>(r, dst, pos, cap, L, lig, gshift, fuel);
+  rc  = block_loop<T, F, R, SYM>(r, dst, pos, cap, L, par, lig, gshift, fuel);
   if (rc == INFL_D_OK && rd_overrun(r)) rc = INFL_D_NEED_INPUT;
   cur = rd_byte_ptr(r);
   if (rc == INFL_D_OK) outlen = pos;
@@ -961,6 +1215,7 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
 // MODE 1: first pass with the compact tables.  A stream that completes writes
 //         its result; any other stream is marked INFL_STATUS_DEFERRED.
 // MODE 2: second pass: only streams marked INFL_STATUS_DEFERRED are decoded.
+// MODE 3: like MODE 1, but a whole wavefront decodes each Huffman block in parallel (T = 64).
 template <int T, class F, int MODE>
 __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restrict__ src,
                                                         const uint64_t *__restrict__ src_off,
@@ -972,8 +1227,14 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
                                                         int32_t *__restrict__ detail,
                                                         uint32_t *__restrict__ inpos) {
   constexpr int  G    = 64 / T;                    // streams per wavefront
-  constexpr bool FAST = MODE == 1;
+  constexpr int  SYM  = MODE == 1 ? 1 : MODE == 3 ? 2 : 0;
+  static_assert(MODE != 3 || T == 64, "the parallel block decoder uses the whole wavefront");
   __shared__ StreamLds<F> lds[G];
+  ParLds *parp = nullptr;
+  if constexpr (MODE == 3) {
+    __shared__ ParLds par;
+    parp = &par;
+  }
 
   const int      lane   = threadIdx.x;
   const int      group  = lane / T;
@@ -989,16 +1250,17 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
   uint32_t       out = 0, pos = 0;
   const uint8_t *cur = nullptr;
   int rc;
-  if constexpr (FAST)
-    rc = inflate_stream<T, F, FastReader<T>, true>(src + s0, (uint32_t)(s1 - s0), dst + d0,
-                                                (uint32_t)(d1 - d0), (flags & 0xff) == 1,
-                                                lds[group], lig, gshift, out, pos, cur);
+  if constexpr (SYM != 0)
+    rc = inflate_stream<T, F, FastReader<T>, SYM>(src + s0, (uint32_t)(s1 - s0), dst + d0,
+                                                  (uint32_t)(d1 - d0), (flags & 0xff) == 1,
+                                                  lds[group], parp, lig,
+                                                  gshift, out, pos, cur);
   else
-    rc = inflate_stream<T, F, Reader, false>(src + s0, (uint32_t)(s1 - s0), dst + d0,
-                                             (uint32_t)(d1 - d0), (flags & 0xff) == 1, lds[group],
-                                             lig, gshift, out, pos, cur);
+    rc = inflate_stream<T, F, Reader, 0>(src + s0, (uint32_t)(s1 - s0), dst + d0,
+                                         (uint32_t)(d1 - d0), (flags & 0xff) == 1, lds[group],
+                                         nullptr, lig, gshift, out, pos, cur);
   if (lig == 0) {
-    if (MODE == 1 && rc != INFL_D_OK) {
+    if ((MODE == 1 || MODE == 3) && rc != INFL_D_OK) {
       status[i] = INFL_STATUS_DEFERRED;
       return;
     }
@@ -1013,6 +1275,9 @@ __global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restric
 
 // variant 0: reference-geometry tables only (one launch).
 // variant 1: compact tables first, reference-geometry tables for what they defer (two launches).
+// variant 2: wavefront-parallel block decode first (one wavefront per stream), then as variant 1
+//            for what it defers.
+// variant 3: diagnostic: the parallel pass alone; deferred streams keep INFL_STATUS_DEFERRED.
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                                  uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
@@ -1028,9 +1293,12 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
 #define LAUNCH_T(T)             \
   if (variant == 0) {           \
     LAUNCH(T, RefFmt, 0);       \
-  } else {                      \
+  } else if (variant == 1) {    \
     LAUNCH(T, CompactFmt, 1);   \
     LAUNCH(T, RefFmt, 2);       \
+  } else {                      \
+    LAUNCH(64, CompactFmt, 3);  \
+    if (variant == 2) LAUNCH(T, RefFmt, 2); \
   }
   switch (lanes) {
     case 64: LAUNCH_T(64) break;

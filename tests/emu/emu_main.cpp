@@ -67,6 +67,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
 extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
                               int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
                               uint32_t *inpos, int lanes, int variant) {
+  if (variant >= 2) lanes = 64;   // the parallel pass is a 64-lane kernel; one group size per run here
   emu::g_lanes_per_group = lanes;
   return infl_launch_batch(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, variant,
                            nullptr);

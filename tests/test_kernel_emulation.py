@@ -39,7 +39,7 @@ def _compare(oracle, streams, caps, flags, lanes, variant=0):
     return status, outlen, detail
 
 
-@pytest.mark.parametrize("lanes,variant", [(64, 0), (8, 0), (16, 1), (64, 1)])
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (8, 0), (16, 1), (64, 1), (64, 2)])
 def test_emulated_kernel_on_fixtures(oracle, lanes, variant):
     names = [n for n in ALL if os.path.getsize(os.path.join(DATA, "compressed", n)) < 40000]
     streams = [_read("compressed", n) for n in names]
@@ -51,7 +51,7 @@ def test_emulated_kernel_on_fixtures(oracle, lanes, variant):
             assert s == 0, n
 
 
-@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (8, 1), (32, 1)])
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (8, 1), (32, 1), (64, 2)])
 def test_emulated_kernel_on_header_cases(oracle, lanes, variant):
     streams = header_cases()
     _compare(oracle, streams, [4096] * len(streams), 0, lanes, variant)
@@ -65,6 +65,8 @@ def test_emulated_kernel_zlib_and_fuzz(oracle):
     caps = [len(r) for r in raws for _ in range(3)]
     _compare(oracle, good, caps, 1, 32)
     _compare(oracle, good, caps, 1, 16, 1)
+    _compare(oracle, good, caps, 1, 64, 2)
+    _compare(oracle, good, [max(0, c - 1) for c in caps], 1, 64, 2)
     _compare(oracle, good, [max(0, c - 1) for c in caps], 1, 64)
     bad = []
     for t in range(160):
@@ -79,3 +81,5 @@ def test_emulated_kernel_zlib_and_fuzz(oracle):
     _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 64)
     _compare(oracle, bad, [8000] * len(bad), 0, 8)
     _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 8, 1)
+    _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 64, 2)
+    _compare(oracle, bad, [8000] * len(bad), 0, 64, 2)
