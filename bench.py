@@ -11,7 +11,7 @@ infl_batch_dev launch) over the rank's batch.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
-import multiprocessing as mp
+from concurrent.futures import ThreadPoolExecutor
 import os
 import sys
 import time
@@ -33,10 +33,12 @@ def _make_stream(i):
 
 
 def build_pool(first, count, workers):
+    """Threads, not processes: a fork after the HIP runtime is up (a profiler preloads it before
+    main) can deadlock the children.  zlib and numpy release the GIL for most of the work."""
     idx = list(range(first, first + count))
     if workers > 1:
-        with mp.get_context("fork").Pool(workers) as pool:
-            return pool.map(_make_stream, idx, chunksize=max(1, count // (workers * 4)))
+        with ThreadPoolExecutor(workers) as pool:
+            return list(pool.map(_make_stream, idx))
     return [_make_stream(i) for i in idx]
 
 
@@ -67,6 +69,12 @@ def cpu_baseline(comps, oracle, threads, budget_s):
         "sample": "%d distinct streams of this workload x %d passes, %d threads; 1 thread: %.0f MB/s"
                   % (len(comps), reps, threads, int(ol1.sum()) / t1 / 1e6),
     }
+
+
+def note(msg):
+    """Progress on stderr (stdout carries only the JSON line)."""
+    if os.environ.get("RANK", "0") == "0":
+        print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -104,6 +112,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    note("torch ready, loading engine")
     eng = capi.load()
     if eng.lib.infl_gpu_init(local) != 0:
         raise SystemExit("infl_gpu_init failed")
@@ -111,8 +120,10 @@ def main():
     eng.lib.infl_gpu_set_table_variant(args.variant)
 
     n, pool = args.streams, min(args.pool, args.streams)
-    workers = max(1, min(8, (os.cpu_count() or 8) // max(1, world)))
+    workers = 4
+    note("generating %d streams with %d workers" % (pool, workers))
     comps = build_pool(rank * pool, pool, workers)
+    note("uploading")
 
     # device layout: one contiguous src arena + u64 offsets, dst arena with 64 KiB stride
     reps = (n + pool - 1) // pool
@@ -143,9 +154,11 @@ def main():
         if world > 1:
             dist.barrier()
 
+    note("warm-up")
     for _ in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
+    note("parity gate")
 
     # parity gate: every stream complete, and the first `pool` outputs bit-exact vs the oracle
     from tests import oracle_lib
@@ -165,6 +178,7 @@ def main():
           for _ in range(args.steps)]
     barrier()
     torch.cuda.synchronize()
+    note("timing %d steps" % args.steps)
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
@@ -238,6 +252,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:
+            note("cpu baseline")
             threads = max(1, min(16, os.cpu_count() or 1))
             res["cpu_baseline"] = cpu_baseline(comps[: min(pool, 1024)], oracle, threads, 12.0)
         print(json.dumps(res), flush=True)

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libdefl_amd.so")
+SO = os.environ.get("DEFL_AMD_LIB") or os.path.join(HERE, "libdefl_amd.so")   # override: diagnostic builds
 CSRC = os.path.join(HERE, "csrc")
 
 UNZ_UNFINISHED, UNZ_NOOP, UNZ_OK, UNZ_ERR, UNZ_EFULL = 2, 1, 0, -1, -105

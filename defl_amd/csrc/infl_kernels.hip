@@ -853,17 +853,49 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
 // returns false and the stream is decoded again by the serial second pass, so
 // this function only has to be right when it succeeds.
 // ---------------------------------------------------------------------------
-constexpr int      PAR_S        = 256;               // sub-sequence length in bits
-constexpr int      PAR_R        = 6144;              // output bytes per round (LDS links)
-constexpr int      PAR_IN       = 2 * PAR_S + 6;     // staged input words: 64 * PAR_S bits + slack
+#ifndef DEFL_PAR_S
+#define DEFL_PAR_S 256
+#endif
+#ifndef DEFL_PAR_R
+#define DEFL_PAR_R 6144
+#endif
+constexpr int      PAR_S        = DEFL_PAR_S;        // sub-sequence length in bits
+constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per round (LDS links)
+constexpr int      PAR_IN       = 2 * PAR_S + 8;     // staged input words: 64 * PAR_S bits + slack
 constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane stops scanning beyond this many bytes
+constexpr int      PAR_U        = 8;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
+// Staged input words are stored transposed: lane l mostly reads words l * PAR_G + k, so word w
+// lives at (w % PAR_G) * PAR_ROW + w / PAR_G and lanes at the same depth k hit distinct banks.
+constexpr int PAR_G   = PAR_S / 32;
+constexpr int PAR_ROW = ((PAR_IN + PAR_G - 1) / PAR_G) | 1;
+static_assert((PAR_G & (PAR_G - 1)) == 0, "sub-sequence length is a power of two");
+
 struct ParLds {
-  uint32_t in[PAR_IN];
+  uint32_t in[PAR_G * PAR_ROW];
   uint16_t link[PAR_R];
 };
+__device__ __forceinline__ uint32_t par_in_at(uint32_t w) {
+  return (w & (uint32_t)(PAR_G - 1)) * (uint32_t)PAR_ROW + w / (uint32_t)PAR_G;
+}
 static_assert(PAR_LANE_CAP + 258 <= PAR_R, "lane 0 always fits a round");
+static_assert(PAR_R <= 0x4000, "internal links are 14-bit indices");
+
+// Optional cycle accounting of the phases (diagnostic builds only: make prof).
+#ifdef DEFL_PAR_PROFILE
+__device__ unsigned long long g_par_prof[16];
+#define PROF_DECL      uint64_t prof_t = __builtin_readcyclecounter(), prof_acc[8] = {}, prof_cnt[4] = {}
+#define PROF_MARK(k)   { uint64_t t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; }
+#define PROF_COUNT(k, v) prof_cnt[k] += (v)
+#define PROF_FLUSH     if (lane == 0) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_par_prof[k_], prof_acc[k_]); \
+                                        for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_par_prof[8 + k_], prof_cnt[k_]); }
+#else
+#define PROF_DECL
+#define PROF_MARK(k)
+#define PROF_COUNT(k, v)
+#define PROF_FLUSH
+#endif
 
 struct ParCtx {
   const uint32_t *in;
@@ -876,69 +908,93 @@ __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
 }
 
-__device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t p) {
-  uint32_t rel = p - c.inbase, w = rel >> 5;
-  uint64_t v = ((uint64_t)c.in[w + 1] << 32) | c.in[w];
-  return (uint32_t)(v >> (rel & 31u));
+// Per-lane bit reader over the staged input words: 33..64 valid bits in a register pair and
+// the following word already loaded, so a table lookup never waits for an input read.
+struct ParBits {
+  uint64_t buf;
+  uint32_t cnt, nw, widx, p;     // valid bits, prefetched word, index of the word after it, bit position
+};
+
+__device__ __forceinline__ void pb_init(ParBits &b, const ParCtx &c, uint32_t p) {
+  uint32_t rel = p - c.inbase, w = rel >> 5, s = rel & 31u;
+  b.buf  = (((uint64_t)c.in[par_in_at(w + 1)] << 32) | c.in[par_in_at(w)]) >> s;
+  b.cnt  = 64u - s;
+  b.nw   = c.in[par_in_at(w + 2)];
+  b.widx = w + 3;
+  b.p    = p;
 }
 
-// One symbol at bit position p.  Returns 0 = none / malformed, 1 = literal (val = byte),
-// 2 = end of block, 3 = match (len, val = distance); pnext = position of the next symbol.
-__device__ __forceinline__ uint32_t par_step(const ParCtx &c, uint32_t p, uint32_t &pnext,
-                                             uint32_t &len, uint32_t &val) {
+__device__ __forceinline__ void pb_refill(ParBits &b, const ParCtx &c) {
+  if (b.cnt <= 32u) {
+    b.buf |= (uint64_t)b.nw << b.cnt;
+    b.cnt += 32u;
+    b.nw = c.in[par_in_at(b.widx)];
+    b.widx++;
+  }
+}
+
+__device__ __forceinline__ void pb_drop(ParBits &b, uint32_t n) {
+  b.buf >>= n;
+  b.cnt -= n;
+  b.p += n;
+}
+
+// One symbol at the reader's position.  Returns 0 = none / malformed, 1 = literal (val = byte),
+// 2 = end of block, 3 = match (len, val = distance); the reader is left behind the symbol.
+__device__ __forceinline__ uint32_t par_step(const ParCtx &c, ParBits &r, uint32_t &len, uint32_t &val) {
   typedef CompactFmt F;
-  uint32_t b = par_peek(c, p);
+  pb_refill(r, c);                                   // >= 33 bits: code (15) + extra (5)
+  uint32_t b = (uint32_t)r.buf;
   uint32_t e = c.lit[b & ((1u << F::LIT_BITS) - 1u)];
   if (e & F::F_SUB) e = c.lit[F::sub_at(e) + ((b >> F::LIT_BITS) & ((1u << (e & 15u)) - 1u))];
   uint32_t cl = e & 15u, kind;
   if (e & F::F_LITERAL) {
-    pnext = p + cl;
-    len   = 1;
-    val   = (e >> 4) & 0xffu;
-    kind  = 1;
+    pb_drop(r, cl);
+    len  = 1;
+    val  = (e >> 4) & 0xffu;
+    kind = 1;
   } else if (!(e & F::F_BASE)) {
-    pnext = p + cl;
-    len   = 0;
-    val   = 0;
-    kind  = e ? 2u : 0u;
+    pb_drop(r, cl);
+    len  = 0;
+    val  = 0;
+    kind = e ? 2u : 0u;
   } else {
     uint32_t xb = (e & F::F_L258) ? 0u : F::xbits(e);
     len = F::len_base(e) + ((b >> cl) & ((1u << xb) - 1u));
-    uint32_t q = p + cl + xb;
-    b = par_peek(c, q);
+    pb_drop(r, cl + xb);
+    pb_refill(r, c);                                 // >= 33 bits: code (15) + extra (13)
+    b = (uint32_t)r.buf;
     e = c.dist[b & ((1u << F::DIST_BITS) - 1u)];
     if (e & F::F_SUB) e = c.dist[F::sub_at(e) + ((b >> F::DIST_BITS) & ((1u << (e & 15u)) - 1u))];
-    cl    = e & 15u;
-    xb    = F::xbits(e);
-    val   = F::dist_base(e) + ((b >> cl) & ((1u << xb) - 1u));
-    pnext = q + cl + xb;
-    kind  = e ? 3u : 0u;
+    cl  = e & 15u;
+    xb  = F::xbits(e);
+    val = F::dist_base(e) + ((b >> cl) & ((1u << xb) - 1u));
+    pb_drop(r, cl + xb);
+    kind = e ? 3u : 0u;
   }
-  if (pnext > c.total_bits) kind = 0;                // would need bits past the end of the stream
+  if (r.p > c.total_bits) kind = 0;                  // would need bits past the end of the stream
   return kind;
 }
 
 // stop: 0 = left the sub-sequence (or hit the byte cap), 1 = end of block, 2 = malformed
 __device__ __forceinline__ void par_scan(const ParCtx &c, uint32_t start, uint32_t limit,
                                          uint32_t &exit, uint32_t &nout, uint32_t &stop) {
-  uint32_t p = start, o = 0, st = 0;
-  while (p < limit && !st && o < PAR_LANE_CAP) {
-    uint32_t pn, len, val;
-    uint32_t kind = par_step(c, p, pn, len, val);
-    if (kind == 0) {
-      st = 2;
-    } else {
-      p = pn;
-      if (kind == 2) st = 1;
-      else o += len;
-    }
+  ParBits  r;
+  uint32_t o = 0, st = 0;
+  pb_init(r, c, start);
+  while (r.p < limit && !st && o < PAR_LANE_CAP) {
+    uint32_t len, val;
+    uint32_t kind = par_step(c, r, len, val);
+    if (kind == 0) st = 2;
+    else if (kind == 2) st = 1;
+    else o += len;
   }
-  exit = p;
+  exit = r.p;
   nout = o;
   stop = st;
 }
 
-__device__ __noinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
+__device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
                                                     uint32_t cap, const uint16_t *lit,
                                                     const uint16_t *dist, ParLds &P, int lane) {
   uint32_t       pos        = pos_io;
@@ -946,22 +1002,27 @@ __device__ __noinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *
   const uint32_t total_bits = r.ilen * 8u;
   uint32_t       guard      = total_bits + 8u;       // every round consumes at least one bit
   bool           done       = false;
+  PROF_DECL;
 
   while (!done) {
     if (guard-- == 0) return false;
+    PROF_COUNT(0, 1);
 
     // stage the input of this round (coalesced, clamped inside the stream, zero padded)
     const uint32_t inbyte = (B >> 3) & ~3u;
     group_sync();
-    for (uint32_t w = lane; w < (uint32_t)PAR_IN; w += 64) {
+#pragma unroll
+    for (int u = 0; u < (PAR_IN + 63) / 64; u++) {
+      uint32_t w   = (uint32_t)(u * 64 + lane);
       uint32_t off = inbyte + 4u * w;
       uint32_t q   = off < r.ilen4 ? off : r.ilen4;
       uint32_t raw;
       __builtin_memcpy(&raw, r.src + q, 4);
       uint32_t d = off - q;
-      P.in[w] = d >= 4 ? 0u : raw >> (8u * d);
+      if (w < (uint32_t)PAR_IN) P.in[par_in_at(w)] = d >= 4 ? 0u : raw >> (8u * d);
     }
     group_sync();
+    PROF_MARK(0);
     ParCtx c;
     c.in         = P.in;
     c.inbase     = inbyte * 8u;
@@ -973,18 +1034,21 @@ __device__ __noinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *
     const uint32_t limit = B + (uint32_t)(lane + 1) * PAR_S;
     uint32_t       start = B + (uint32_t)lane * PAR_S, exit, nout, stop;
     par_scan(c, start, limit, exit, nout, stop);
+    PROF_MARK(1);
     for (int iter = 0; iter < 64; iter++) {
       uint32_t pe       = wave_read(exit, lane ? lane - 1 : 0);
       uint64_t stopmask = __ballot(stop != 0);
       bool     dead     = (stopmask & ((1ull << lane) - 1ull)) != 0;   // behind the end of the block
       bool     changed  = lane > 0 && !dead && pe != start;
       if (!__ballot(changed)) break;
+      PROF_COUNT(1, 1);
       if (changed) {
         start = pe;
         par_scan(c, start, limit, exit, nout, stop);
       }
     }
 
+    PROF_MARK(2);
     // 3. place
     const uint64_t stopmask   = __ballot(stop != 0);
     const uint32_t first_stop = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : 64u;
@@ -1000,54 +1064,102 @@ __device__ __noinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *
     const uint32_t total_out = wave_read(cum, m - 1);
     if (total_out > cap - pos) return false;
 
-    // 4. emit links
+    PROF_MARK(3);
+    PROF_COUNT(3, m);
+    // 4. emit links: every pass of the loop decodes the lane's next symbol (unless a match is
+    //    still being written) and writes up to 8 links of the pending match
     bool bad = false;
-    if ((uint32_t)lane < m) {
-      uint32_t p = start, o = cum - nout;
-      while (p < exit) {
-        uint32_t pn, len, val;
-        uint32_t kind = par_step(c, p, pn, len, val);
-        if (kind == 1) {
-          P.link[o] = (uint16_t)(LK_LIT | val);
-          o++;
-        } else if (kind == 3) {
-          if (val > pos + o) {                       // distance reaches before the output start
-            bad = true;
-            break;
+    {
+      ParBits  rb;
+      bool     act = (uint32_t)lane < m;
+      uint32_t o = cum - nout, rem = 0;
+      int32_t  j = 0;
+      pb_init(rb, c, act ? start : B);
+      while (__ballot(act)) {
+        if (act && rem == 0) {
+          if (rb.p >= exit) {
+            act = false;
+          } else {
+            uint32_t len, val;
+            uint32_t kind = par_step(c, rb, len, val);
+            if (kind == 1) {
+              P.link[o] = (uint16_t)(LK_LIT | val);
+              o++;
+            } else if (kind == 3 && val <= pos + o) {
+              rem = len;
+              j   = (int32_t)o - (int32_t)val;
+            } else {
+              bad = kind == 3;                       // distance reaches before the output start
+              act = false;                           // or the end-of-block code
+            }
           }
-          for (uint32_t k = 0; k < len; k++) {
-            uint32_t i = o + k;
-            P.link[i] = (uint16_t)(val > i ? LK_EXT | (val - i - 1u) : i - val);
-          }
-          o += len;
-        } else {
-          break;                                     // end of block (malformed cannot happen here)
         }
-        p = pn;
+        if (act && rem) {
+          uint32_t n = rem < 8u ? rem : 8u;
+#pragma unroll
+          for (uint32_t k = 0; k < 8; k++) {
+            int32_t jj = j + (int32_t)k;
+            if (k < n) P.link[o + k] = (uint16_t)(jj >= 0 ? (uint32_t)jj : LK_EXT | (uint32_t)(-jj - 1));
+          }
+          o += n;
+          j += (int32_t)n;
+          rem -= n;
+        }
       }
     }
     if (__ballot(bad)) return false;
     group_sync();
+    PROF_MARK(4);
 
-    // 5. resolve: bytes from before this round, then pointer jumping, then write out
-    for (uint32_t i = lane; i < total_out; i += 64) {
-      uint32_t v = P.link[i];
-      if (v & LK_EXT) P.link[i] = (uint16_t)(LK_LIT | dst[pos - 1u - (v & 0x7fffu)]);
+    // 5. resolve: bytes from before this round, then pointer jumping, then write out.
+    //    Straight-line bodies (every access is made, harmless ones where nothing is to do) so
+    //    that PAR_U independent accesses are in flight at once.
+    for (uint32_t base = (uint32_t)lane; base < total_out + (uint32_t)lane; base += 64 * PAR_U) {
+      uint32_t v[PAR_U], bt[PAR_U];
+#pragma unroll
+      for (int u = 0; u < PAR_U; u++) {
+        uint32_t i = base + 64u * u;
+        v[u] = P.link[i < total_out ? i : 0u];
+        v[u] = i < total_out ? v[u] : LK_LIT;
+      }
+#pragma unroll
+      for (int u = 0; u < PAR_U; u++) {
+        uint32_t back = (v[u] & LK_EXT) ? (v[u] & 0x7fffu) + 1u : (pos ? 1u : 0u);
+        bt[u] = dst[pos - back];
+      }
+#pragma unroll
+      for (int u = 0; u < PAR_U; u++) {
+        uint32_t i = base + 64u * u;
+        if (i < total_out) P.link[i] = (uint16_t)((v[u] & LK_EXT) ? (LK_LIT | bt[u]) : v[u]);
+      }
     }
     group_sync();
+    PROF_MARK(5);
     for (int it = 0; it < 16; it++) {
+      PROF_COUNT(2, 1);
       bool more = false;
-      for (uint32_t i = lane; i < total_out; i += 64) {
-        uint32_t v = P.link[i];
-        if (!(v & LK_LIT)) {
-          uint32_t u = P.link[v];
-          P.link[i] = (uint16_t)u;
-          more |= !(u & LK_LIT);
+      for (uint32_t base = (uint32_t)lane; base < total_out + (uint32_t)lane; base += 64 * PAR_U) {
+        uint32_t v[PAR_U], t[PAR_U];
+#pragma unroll
+        for (int u = 0; u < PAR_U; u++) {
+          uint32_t i = base + 64u * u;
+          v[u] = P.link[i < total_out ? i : 0u];
+          v[u] = i < total_out ? v[u] : LK_LIT;
+        }
+#pragma unroll
+        for (int u = 0; u < PAR_U; u++) t[u] = P.link[(v[u] & LK_LIT) ? 0u : v[u]];
+#pragma unroll
+        for (int u = 0; u < PAR_U; u++) {
+          uint32_t i = base + 64u * u;
+          uint32_t nv = (v[u] & LK_LIT) ? v[u] : t[u];
+          if (i < total_out) P.link[i] = (uint16_t)nv;
+          more |= !(nv & LK_LIT);
         }
       }
       group_sync();
       if (!__ballot(more)) break;
     }
+    PROF_MARK(6);
     for (uint32_t i = (uint32_t)lane * 4u; i < total_out; i += 256) {
       if (i + 4 <= total_out) {
         uint64_t q;
@@ -1060,11 +1172,13 @@ __device__ __noinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    PROF_MARK(7);
 
     pos += total_out;
     B    = wave_read(exit, m - 1);
     done = first_stop < m;                           // the end-of-block code has been consumed
   }
+  PROF_FLUSH;
   pos_io = pos;
   rd_seek(r, r.src + (B >> 3));                      // put the serial reader behind the block
   rd_fill(r);
@@ -1311,3 +1425,13 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+#ifdef DEFL_PAR_PROFILE
+// Diagnostic builds only: read (and clear) the phase counters of huffman_block_parallel.
+extern "C" __attribute__((visibility("default"))) int infl_debug_par_profile(unsigned long long *out16) {
+  unsigned long long zero[16] = {};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(defl::g_par_prof), sizeof(zero)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(defl::g_par_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

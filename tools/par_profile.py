@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Cycle accounting of the wavefront-parallel block decoder (diagnostic build: make -C defl_amd/csrc prof).
+
+    DEFL_AMD_LIB=defl_amd/libdefl_amd_prof.so python tools/par_profile.py [--streams N]
+
+Prints the share of wave cycles each phase of huffman_block_parallel takes on the headline
+workload, plus rounds, fix-up rescans, pointer-jumping sweeps and lanes used per round.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+import workloads as wl  # noqa: E402
+
+PHASES = ["stage-in", "first scan", "fix-up", "place", "emit", "fetch-ext", "jump", "write-out"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=8192)
+    ap.add_argument("--pool", type=int, default=256)
+    args = ap.parse_args()
+    from defl_amd import capi
+    eng = capi.load()
+    assert eng.lib.infl_gpu_init(0) == 0
+    fn = eng.lib.infl_debug_par_profile
+    fn.argtypes = [C.POINTER(C.c_ulonglong)]
+    eng.lib.infl_gpu_set_table_variant(2)
+    comps = bench.build_pool(0, args.pool, 4)
+    comps = (comps * ((args.streams + args.pool - 1) // args.pool))[: args.streams]
+    src, src_off, dst_off = wl.pack(comps, [bench.STREAM_BYTES] * len(comps))
+    b = eng.device_batch(src, src_off, dst_off)
+    buf = (C.c_ulonglong * 16)()
+    b.run(1, detail=False)
+    assert fn(buf) == 0                      # warm-up, cleared
+    b.run(1, detail=False)
+    assert fn(buf) == 0
+    v = np.array(list(buf), dtype=np.float64)
+    _, status, outlen, _ = b.results(want_dst=False)
+    assert (status == 0).all()
+    tot = v[:8].sum()
+    n = len(comps)
+    print("streams %d; wave cycles per stream %.0f" % (n, tot / n))
+    for k, name in enumerate(PHASES):
+        print("  %-11s %6.2f %%  %9.0f cycles/stream" % (name, 100 * v[k] / tot, v[k] / n))
+    rounds = v[8]
+    print("rounds/stream %.2f; rescans/round %.2f; sweeps/round %.2f; lanes/round %.1f"
+          % (rounds / n, v[9] / rounds, v[10] / rounds, v[11] / rounds))
+
+
+if __name__ == "__main__":
+    main()
