@@ -857,7 +857,7 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
 #define DEFL_PAR_S 256
 #endif
 #ifndef DEFL_PAR_R
-#define DEFL_PAR_R 6144
+#define DEFL_PAR_R 2048
 #endif
 constexpr int      PAR_S        = DEFL_PAR_S;        // sub-sequence length in bits
 constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per round (LDS links)
@@ -872,9 +872,12 @@ constexpr int PAR_G   = PAR_S / 32;
 constexpr int PAR_ROW = ((PAR_IN + PAR_G - 1) / PAR_G) | 1;
 static_assert((PAR_G & (PAR_G - 1)) == 0, "sub-sequence length is a power of two");
 
-struct ParLds {
+#ifndef DEFL_PAR_PAD
+#define DEFL_PAR_PAD 0                               // experiments: extra LDS per wave (lowers occupancy)
+#endif
+struct alignas(16) ParLds {
   uint32_t in[PAR_G * PAR_ROW];
-  uint16_t link[PAR_R];
+  uint16_t link[PAR_R + 8 + DEFL_PAR_PAD / 2];       // 8: slack for whole-word reads at the end
 };
 __device__ __forceinline__ uint32_t par_in_at(uint32_t w) {
   return (w & (uint32_t)(PAR_G - 1)) * (uint32_t)PAR_ROW + w / (uint32_t)PAR_G;
@@ -885,11 +888,11 @@ static_assert(PAR_R <= 0x4000, "internal links are 14-bit indices");
 // Optional cycle accounting of the phases (diagnostic builds only: make prof).
 #ifdef DEFL_PAR_PROFILE
 __device__ unsigned long long g_par_prof[16];
-#define PROF_DECL      uint64_t prof_t = __builtin_readcyclecounter(), prof_acc[8] = {}, prof_cnt[4] = {}
+#define PROF_DECL      uint64_t prof_t = __builtin_readcyclecounter(), prof_acc[10] = {}, prof_cnt[4] = {}
 #define PROF_MARK(k)   { uint64_t t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; }
 #define PROF_COUNT(k, v) prof_cnt[k] += (v)
-#define PROF_FLUSH     if (lane == 0) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_par_prof[k_], prof_acc[k_]); \
-                                        for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_par_prof[8 + k_], prof_cnt[k_]); }
+#define PROF_FLUSH     if (lane == 0) { for (int k_ = 0; k_ < 10; k_++) atomicAdd(&g_par_prof[k_], prof_acc[k_]); \
+                                        for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_par_prof[10 + k_], prof_cnt[k_]); }
 #else
 #define PROF_DECL
 #define PROF_MARK(k)
@@ -908,90 +911,117 @@ __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
 }
 
-// Per-lane bit reader over the staged input words: 33..64 valid bits in a register pair and
-// the following word already loaded, so a table lookup never waits for an input read.
-struct ParBits {
+// Per-lane decoder state over the staged input words: 33..64 valid bits in a register pair
+// and the following word already loaded, so a table lookup never waits for an input read.
+// One step decodes ONE code: a literal/length code (ph = 0) or, after a length code, the
+// distance code (ph = 1).  The step is straight-line code (selects, no divergent branches):
+// all 64 lanes run it together whatever kind of code each of them meets.
+struct ParLane {
   uint64_t buf;
   uint32_t cnt, nw, widx, p;     // valid bits, prefetched word, index of the word after it, bit position
+  uint32_t ph, o, st;            // phase, bytes produced, stop reason (0 none, 1 end of block, 2 malformed)
 };
 
-__device__ __forceinline__ void pb_init(ParBits &b, const ParCtx &c, uint32_t p) {
+__device__ __forceinline__ void pl_init(ParLane &b, const ParCtx &c, uint32_t p) {
   uint32_t rel = p - c.inbase, w = rel >> 5, s = rel & 31u;
   b.buf  = (((uint64_t)c.in[par_in_at(w + 1)] << 32) | c.in[par_in_at(w)]) >> s;
   b.cnt  = 64u - s;
   b.nw   = c.in[par_in_at(w + 2)];
   b.widx = w + 3;
   b.p    = p;
+  b.ph   = 0;
+  b.o    = 0;
+  b.st   = 0;
 }
 
-__device__ __forceinline__ void pb_refill(ParBits &b, const ParCtx &c) {
-  if (b.cnt <= 32u) {
-    b.buf |= (uint64_t)b.nw << b.cnt;
-    b.cnt += 32u;
-    b.nw = c.in[par_in_at(b.widx)];
-    b.widx++;
-  }
-}
-
-__device__ __forceinline__ void pb_drop(ParBits &b, uint32_t n) {
-  b.buf >>= n;
-  b.cnt -= n;
-  b.p += n;
-}
-
-// One symbol at the reader's position.  Returns 0 = none / malformed, 1 = literal (val = byte),
-// 2 = end of block, 3 = match (len, val = distance); the reader is left behind the symbol.
-__device__ __forceinline__ uint32_t par_step(const ParCtx &c, ParBits &r, uint32_t &len, uint32_t &val) {
+// Decodes the code at the lane's position.  `value`: literal byte, match length or distance - 1.
+// Returns the entry kind: 1 = literal, 2 = end of block, 3 = length, 4 = distance, 0 = malformed.
+__device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_t &value) {
   typedef CompactFmt F;
-  pb_refill(r, c);                                   // >= 33 bits: code (15) + extra (5)
-  uint32_t b = (uint32_t)r.buf;
-  uint32_t e = c.lit[b & ((1u << F::LIT_BITS) - 1u)];
-  if (e & F::F_SUB) e = c.lit[F::sub_at(e) + ((b >> F::LIT_BITS) & ((1u << (e & 15u)) - 1u))];
-  uint32_t cl = e & 15u, kind;
-  if (e & F::F_LITERAL) {
-    pb_drop(r, cl);
-    len  = 1;
-    val  = (e >> 4) & 0xffu;
-    kind = 1;
-  } else if (!(e & F::F_BASE)) {
-    pb_drop(r, cl);
-    len  = 0;
-    val  = 0;
-    kind = e ? 2u : 0u;
+  // refill to >= 33 bits (a code and its extra bits take at most 28)
+  const bool     need = r.cnt <= 32u;
+  const uint64_t add  = (uint64_t)r.nw << (r.cnt & 63u);
+  const uint32_t nxt  = c.in[par_in_at(r.widx)];
+  r.buf |= need ? add : 0ull;
+  r.cnt += need ? 32u : 0u;
+  r.nw = need ? nxt : r.nw;
+  r.widx += need ? 1u : 0u;
+
+  const uint32_t  b     = (uint32_t)r.buf;
+  const uint32_t  mbits = r.ph ? (uint32_t)F::DIST_BITS : (uint32_t)F::LIT_BITS;
+  const uint16_t *tab   = r.ph ? c.dist : c.lit;
+  uint32_t        e     = tab[b & ((1u << mbits) - 1u)];
+  if (e & F::F_SUB)                                  // second-level table (skipped when no lane needs it)
+    e = tab[F::sub_at(e) + ((b >> mbits) & ((1u << (e & 15u)) - 1u))];
+  const uint32_t cl     = e & 15u;
+  const bool     islit  = (e & F::F_LITERAL) != 0;
+  const bool     isbase = !islit && (e & F::F_BASE) != 0;
+  const uint32_t x      = isbase ? (e >> 4) & 15u : 0u;
+  const uint32_t extra  = (b >> cl) & ((1u << x) - 1u);
+  const uint32_t mant   = (((e >> 8) & 7u) << x) + extra;
+  const uint32_t n      = cl + x;
+  r.buf >>= n;
+  r.cnt -= n;
+  r.p += n;
+
+  uint32_t kind;
+  if (r.ph) {
+    kind  = isbase ? 4u : 0u;
+    value = mant;                                    // distance - 1
+    r.ph  = 0;
   } else {
-    uint32_t xb = (e & F::F_L258) ? 0u : F::xbits(e);
-    len = F::len_base(e) + ((b >> cl) & ((1u << xb) - 1u));
-    pb_drop(r, cl + xb);
-    pb_refill(r, c);                                 // >= 33 bits: code (15) + extra (13)
-    b = (uint32_t)r.buf;
-    e = c.dist[b & ((1u << F::DIST_BITS) - 1u)];
-    if (e & F::F_SUB) e = c.dist[F::sub_at(e) + ((b >> F::DIST_BITS) & ((1u << (e & 15u)) - 1u))];
-    cl  = e & 15u;
-    xb  = F::xbits(e);
-    val = F::dist_base(e) + ((b >> cl) & ((1u << xb) - 1u));
-    pb_drop(r, cl + xb);
-    kind = e ? 3u : 0u;
+    const uint32_t len = (e & F::F_L258) ? 258u : 3u + mant;
+    kind  = islit ? 1u : isbase ? 3u : (e ? 2u : 0u);
+    value = islit ? (e >> 4) & 0xffu : len;
+    r.o += islit ? 1u : isbase ? len : 0u;
+    r.ph = isbase ? 1u : 0u;
   }
   if (r.p > c.total_bits) kind = 0;                  // would need bits past the end of the stream
+  r.st = kind == 0 ? 2u : kind == 2 ? 1u : 0u;
   return kind;
 }
 
-// stop: 0 = left the sub-sequence (or hit the byte cap), 1 = end of block, 2 = malformed
-__device__ __forceinline__ void par_scan(const ParCtx &c, uint32_t start, uint32_t limit,
-                                         uint32_t &exit, uint32_t &nout, uint32_t &stop) {
-  ParBits  r;
-  uint32_t o = 0, st = 0;
-  pb_init(r, c, start);
-  while (r.p < limit && !st && o < PAR_LANE_CAP) {
-    uint32_t len, val;
-    uint32_t kind = par_step(c, r, len, val);
-    if (kind == 0) st = 2;
-    else if (kind == 2) st = 1;
-    else o += len;
+// a lane goes on while it is inside a match, or inside its sub-sequence and under the byte cap
+__device__ __forceinline__ bool pl_more(const ParLane &r, uint32_t limit) {
+  return !r.st && (r.ph || (r.p < limit && r.o < PAR_LANE_CAP));
+}
+
+// Result of scanning one sub-sequence.  ck[k-1] (k = 1..3) packs the chain's state at its
+// first symbol boundary at or behind quarter k of the sub-sequence, so that four lanes can
+// later re-walk one chain: (bit position - round start) << 11 | bytes produced so far.
+struct ParScan {
+  uint32_t exit, nout, stop;     // stop: 0 = left the sub-sequence (or hit the byte cap), 1 = end of block, 2 = malformed
+  uint32_t ck[3];
+};
+constexpr int PAR_Q = PAR_S / 4;                     // bits per quarter
+static_assert(PAR_Q >= 48, "a symbol (48 bits at most) never skips a quarter");
+static_assert(PAR_LANE_CAP + 258 < (1u << 11) && 64 * PAR_S + 64 < (1 << 15), "checkpoint packing");
+
+__device__ __forceinline__ void par_scan(const ParCtx &c, uint32_t round0, uint32_t nominal,
+                                         uint32_t start, ParScan &s) {
+  ParLane  r;
+  uint32_t k = 1, nb = nominal + PAR_Q;              // next checkpoint and its bit position
+  const uint32_t limit = nominal + PAR_S;
+  s.ck[0] = s.ck[1] = s.ck[2] = 0;
+  pl_init(r, c, start);
+  while (pl_more(r, limit)) {
+    uint32_t value;
+    pl_step(r, c, value);
+    const bool     hit = !r.ph && r.p >= nb && k <= 3;
+    const uint32_t pk  = ((r.p - round0) << 11) | r.o;
+    s.ck[0] = hit && k == 1 ? pk : s.ck[0];
+    s.ck[1] = hit && k == 2 ? pk : s.ck[1];
+    s.ck[2] = hit && k == 3 ? pk : s.ck[2];
+    k += hit ? 1u : 0u;
+    nb += hit ? (uint32_t)PAR_Q : 0u;
   }
-  exit = r.p;
-  nout = o;
-  stop = st;
+  const uint32_t fin = ((r.p - round0) << 11) | r.o; // quarters the chain never reached are empty
+  s.ck[0] = k <= 1 ? fin : s.ck[0];
+  s.ck[1] = k <= 2 ? fin : s.ck[1];
+  s.ck[2] = k <= 3 ? fin : s.ck[2];
+  s.exit = r.p;
+  s.nout = r.o;
+  s.stop = r.st;
 }
 
 __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
@@ -1031,152 +1061,201 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     c.dist       = dist;
 
     // 1. scan, 2. fix up
-    const uint32_t limit = B + (uint32_t)(lane + 1) * PAR_S;
-    uint32_t       start = B + (uint32_t)lane * PAR_S, exit, nout, stop;
-    par_scan(c, start, limit, exit, nout, stop);
+    const uint32_t nominal = B + (uint32_t)lane * PAR_S;
+    uint32_t       start   = nominal;
+    ParScan        sc;
+    par_scan(c, B, nominal, start, sc);
     PROF_MARK(1);
     for (int iter = 0; iter < 64; iter++) {
-      uint32_t pe       = wave_read(exit, lane ? lane - 1 : 0);
-      uint64_t stopmask = __ballot(stop != 0);
+      uint32_t pe       = wave_read(sc.exit, lane ? lane - 1 : 0);
+      uint64_t stopmask = __ballot(sc.stop != 0);
       bool     dead     = (stopmask & ((1ull << lane) - 1ull)) != 0;   // behind the end of the block
       bool     changed  = lane > 0 && !dead && pe != start;
       if (!__ballot(changed)) break;
       PROF_COUNT(1, 1);
       if (changed) {
         start = pe;
-        par_scan(c, start, limit, exit, nout, stop);
+        par_scan(c, B, nominal, start, sc);
       }
     }
 
     PROF_MARK(2);
-    // 3. place
-    const uint64_t stopmask   = __ballot(stop != 0);
+    // 3. place: lanes up to the one that met the end of the block hold the true chain
+    const uint64_t stopmask   = __ballot(sc.stop != 0);
     const uint32_t first_stop = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : 64u;
-    if (first_stop < 64 && wave_read(stop, first_stop) == 2) return false;   // malformed on the true chain
-    const bool active = (uint32_t)lane <= first_stop;
-    uint32_t   cum    = active ? nout : 0;
+    if (first_stop < 64 && wave_read(sc.stop, first_stop) == 2) return false;   // malformed on the true chain
+    const uint32_t nact = first_stop < 64 ? first_stop + 1u : 64u;
+    uint32_t       cum  = (uint32_t)lane < nact ? sc.nout : 0;
     for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
       uint32_t t = wave_read(cum, (uint32_t)lane >= dlt ? lane - dlt : 0);
       if ((uint32_t)lane >= dlt) cum += t;
     }
-    const uint32_t m = (uint32_t)__popcll(__ballot(active && cum <= (uint32_t)PAR_R));
-    if (m == 0) return false;
-    const uint32_t total_out = wave_read(cum, m - 1);
-    if (total_out > cap - pos) return false;
-
+    if (wave_read(cum, nact - 1u) > cap - pos) return false;
     PROF_MARK(3);
-    PROF_COUNT(3, m);
-    // 4. emit links: every pass of the loop decodes the lane's next symbol (unless a match is
-    //    still being written) and writes up to 8 links of the pending match
-    bool bad = false;
-    {
-      ParBits  rb;
-      bool     act = (uint32_t)lane < m;
-      uint32_t o = cum - nout, rem = 0;
-      int32_t  j = 0;
-      pb_init(rb, c, act ? start : B);
-      while (__ballot(act)) {
-        if (act && rem == 0) {
-          if (rb.p >= exit) {
-            act = false;
-          } else {
-            uint32_t len, val;
-            uint32_t kind = par_step(c, rb, len, val);
-            if (kind == 1) {
-              P.link[o] = (uint16_t)(LK_LIT | val);
-              o++;
-            } else if (kind == 3 && val <= pos + o) {
-              rem = len;
-              j   = (int32_t)o - (int32_t)val;
-            } else {
-              bad = kind == 3;                       // distance reaches before the output start
-              act = false;                           // or the end-of-block code
-            }
-          }
-        }
-        if (act && rem) {
-          uint32_t n = rem < 8u ? rem : 8u;
-#pragma unroll
-          for (uint32_t k = 0; k < 8; k++) {
-            int32_t jj = j + (int32_t)k;
-            if (k < n) P.link[o + k] = (uint16_t)(jj >= 0 ? (uint32_t)jj : LK_EXT | (uint32_t)(-jj - 1));
-          }
-          o += n;
-          j += (int32_t)n;
-          rem -= n;
-        }
-      }
-    }
-    if (__ballot(bad)) return false;
-    group_sync();
-    PROF_MARK(4);
 
-    // 5. resolve: bytes from before this round, then pointer jumping, then write out.
-    //    Straight-line bodies (every access is made, harmless ones where nothing is to do) so
-    //    that PAR_U independent accesses are in flight at once.
-    for (uint32_t base = (uint32_t)lane; base < total_out + (uint32_t)lane; base += 64 * PAR_U) {
-      uint32_t v[PAR_U], bt[PAR_U];
-#pragma unroll
-      for (int u = 0; u < PAR_U; u++) {
-        uint32_t i = base + 64u * u;
-        v[u] = P.link[i < total_out ? i : 0u];
-        v[u] = i < total_out ? v[u] : LK_LIT;
+    // The round's output is produced in groups of up to 16 consecutive chains whose bytes fit
+    // the link buffer; four lanes share a chain (one quarter each) while the links are written.
+    uint32_t a = 0;
+    while (a < nact) {
+      const uint32_t base_cum = a ? wave_read(cum, a - 1u) : 0u;
+      const bool     fits     = (uint32_t)lane >= a && (uint32_t)lane < nact && (uint32_t)lane < a + 16u &&
+                            cum - base_cum <= (uint32_t)PAR_R;
+      const uint32_t nch = (uint32_t)__popcll(__ballot(fits));
+      if (nch == 0) return false;                    // cannot happen: one chain always fits
+      const uint32_t total_out = wave_read(cum, a + nch - 1u) - base_cum;
+      PROF_COUNT(3, nch);
+
+      // 4. emit: clear the group's links, then walk the chains once more and write one "head"
+      //    per symbol at the symbol's first byte: a literal value, or a match as
+      //    LK_EXT | (distance - 1).  Bytes inside a match stay 0.
+      group_sync();
+      for (uint32_t i = (uint32_t)lane * 8u; i < total_out; i += 512) {
+        uint4 z = {0u, 0u, 0u, 0u};
+        __builtin_memcpy(&P.link[i], &z, 16);
       }
-#pragma unroll
-      for (int u = 0; u < PAR_U; u++) {
-        uint32_t back = (v[u] & LK_EXT) ? (v[u] & 0x7fffu) + 1u : (pos ? 1u : 0u);
-        bt[u] = dst[pos - back];
-      }
-#pragma unroll
-      for (int u = 0; u < PAR_U; u++) {
-        uint32_t i = base + 64u * u;
-        if (i < total_out) P.link[i] = (uint16_t)((v[u] & LK_EXT) ? (LK_LIT | bt[u]) : v[u]);
-      }
-    }
-    group_sync();
-    PROF_MARK(5);
-    for (int it = 0; it < 16; it++) {
-      PROF_COUNT(2, 1);
-      bool more = false;
-      for (uint32_t base = (uint32_t)lane; base < total_out + (uint32_t)lane; base += 64 * PAR_U) {
-        uint32_t v[PAR_U], t[PAR_U];
-#pragma unroll
-        for (int u = 0; u < PAR_U; u++) {
-          uint32_t i = base + 64u * u;
-          v[u] = P.link[i < total_out ? i : 0u];
-          v[u] = i < total_out ? v[u] : LK_LIT;
+      bool bad = false;
+      {
+        const uint32_t ch  = a + ((uint32_t)lane >> 2), q = (uint32_t)lane & 3u;
+        const uint32_t chl = ch < 64u ? ch : 63u;
+        const uint32_t cs  = wave_read(start, chl), ce = wave_read(sc.exit, chl);
+        const uint32_t o0  = wave_read(cum - sc.nout, chl) - base_cum;
+        const uint32_t k1 = wave_read(sc.ck[0], chl), k2 = wave_read(sc.ck[1], chl), k3 = wave_read(sc.ck[2], chl);
+        const uint32_t kb = q == 1 ? k1 : q == 2 ? k2 : k3;      // state at the quarter's begin
+        const uint32_t ke = q == 0 ? k1 : q == 1 ? k2 : k3;      // and at its end
+        const uint32_t pb = q ? B + (kb >> 11) : cs;
+        const uint32_t pe = q < 3 ? B + (ke >> 11) : ce;
+        ParLane  rl;
+        uint32_t oh  = 0;
+        bool     act = ch < a + nch && pb < pe;
+        group_sync();
+        pl_init(rl, c, act ? pb : B);
+        rl.o = q ? kb & 0x7ffu : 0u;
+        while (__ballot(act)) {
+          if (act) {
+            uint32_t       value;
+            const uint32_t at   = o0 + rl.o;
+            const uint32_t kind = pl_step(rl, c, value);
+            if (kind == 1) P.link[at] = (uint16_t)(LK_LIT | value);
+            if (kind == 3) oh = at;
+            if (kind == 4) {
+              if (value >= pos + oh) bad = true;     // distance reaches before the output start
+              P.link[oh] = (uint16_t)(LK_EXT | value);
+            }
+            act = !bad && !rl.st && (rl.ph || rl.p < pe);
+          }
         }
+      }
+      if (__ballot(bad)) return false;
+      group_sync();
+      PROF_MARK(4);
+
+      // 5a. expand: every byte finds the head at or before it (ballot + count-leading-zeros
+      //     inside a 64-byte chunk, the last head of earlier chunks carried along) and becomes a
+      //     literal, an index of an earlier byte of the group, or LK_EXT | how far before it.
+      {
+        const uint64_t le    = ~0ull >> (63 - lane); // lanes at or below this one
+        uint32_t       carry = 0;
+        for (uint32_t base = 0; base < total_out; base += 256) {
+          uint32_t h[4], d[4];
+          uint64_t heads[4];
+          bool     own[4];
 #pragma unroll
-        for (int u = 0; u < PAR_U; u++) t[u] = P.link[(v[u] & LK_LIT) ? 0u : v[u]];
+          for (int u = 0; u < 4; u++) {
+            const uint32_t i = base + 64u * u + (uint32_t)lane;
+            h[u] = P.link[i < total_out ? i : 0u];
+            h[u] = i < total_out ? h[u] : 0u;
+          }
 #pragma unroll
-        for (int u = 0; u < PAR_U; u++) {
-          uint32_t i = base + 64u * u;
-          uint32_t nv = (v[u] & LK_LIT) ? v[u] : t[u];
-          if (i < total_out) P.link[i] = (uint16_t)nv;
-          more |= !(nv & LK_LIT);
+          for (int u = 0; u < 4; u++) {
+            heads[u] = __ballot(h[u] != 0);
+            const uint64_t mine = heads[u] & le;
+            own[u] = mine != 0;
+            d[u]   = wave_read(h[u], own[u] ? 63u - (uint32_t)__builtin_clzll(mine) : (uint32_t)lane);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t i    = base + 64u * u + (uint32_t)lane;
+            const uint32_t desc = own[u] ? d[u] : carry;
+            if (heads[u]) carry = (uint32_t)__builtin_amdgcn_readlane((int)h[u], 63 - __builtin_clzll(heads[u]));
+            uint32_t out = desc;
+            if (desc & LK_EXT) {
+              const uint32_t dd = (desc & 0x7fffu) + 1u;
+              out = dd <= i ? i - dd : LK_EXT | (dd - i - 1u);
+            }
+            if (i < total_out) P.link[i] = (uint16_t)out;
+          }
         }
       }
       group_sync();
-      if (!__ballot(more)) break;
-    }
-    PROF_MARK(6);
-    for (uint32_t i = (uint32_t)lane * 4u; i < total_out; i += 256) {
-      if (i + 4 <= total_out) {
-        uint64_t q;
-        __builtin_memcpy(&q, &P.link[i], 8);
-        uint32_t w = (uint32_t)(q & 0xffu) | ((uint32_t)(q >> 8) & 0xff00u) |
-                     ((uint32_t)(q >> 16) & 0xff0000u) | ((uint32_t)(q >> 24) & 0xff000000u);
-        __builtin_memcpy(dst + pos + i, &w, 4);
-      } else {
-        for (uint32_t k = i; k < total_out; k++) dst[pos + k] = (uint8_t)P.link[k];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    PROF_MARK(7);
+      PROF_MARK(5);
 
-    pos += total_out;
-    B    = wave_read(exit, m - 1);
-    done = first_stop < m;                           // the end-of-block code has been consumed
+      // 5b. pointer jumping: every link ends at a literal or at a byte from before the group
+      //     (both are position independent, so they can be copied along the chains).  Straight-
+      //     line bodies (every access is made, harmless ones where nothing is to do) so that
+      //     PAR_U independent accesses are in flight at once.
+      for (int it = 0; it < 16; it++) {
+        PROF_COUNT(2, 1);
+        bool more = false;
+        for (uint32_t base = (uint32_t)lane; base < total_out + (uint32_t)lane; base += 64 * PAR_U) {
+          uint32_t v[PAR_U], t[PAR_U];
+#pragma unroll
+          for (int u = 0; u < PAR_U; u++) {
+            uint32_t i = base + 64u * u;
+            v[u] = P.link[i < total_out ? i : 0u];
+            v[u] = i < total_out ? v[u] : LK_LIT;
+          }
+#pragma unroll
+          for (int u = 0; u < PAR_U; u++) t[u] = P.link[(v[u] & (LK_LIT | LK_EXT)) ? 0u : v[u]];
+#pragma unroll
+          for (int u = 0; u < PAR_U; u++) {
+            uint32_t i = base + 64u * u;
+            uint32_t nv = (v[u] & (LK_LIT | LK_EXT)) ? v[u] : t[u];
+            if (i < total_out) P.link[i] = (uint16_t)nv;
+            more |= !(nv & (LK_LIT | LK_EXT));
+          }
+        }
+        group_sync();
+        if (!__ballot(more)) break;
+      }
+      PROF_MARK(6);
+
+      // 5c. write out, four bytes per lane and pass: literals from the links, the others from
+      //     the output before the group (two passes' loads in flight together)
+      for (uint32_t base = (uint32_t)lane * 4u; base < total_out + (uint32_t)lane * 4u; base += 512) {
+        uint32_t by[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const uint32_t i = base + 256u * u;
+          uint64_t       q;
+          __builtin_memcpy(&q, &P.link[i < total_out ? i : 0u], 8);   // up to 3 entries of slack behind
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t v    = (uint32_t)(q >> (16 * k)) & 0xffffu;
+            const bool     ext  = (v & LK_EXT) && i + k < total_out;
+            const uint32_t back = ext ? (v & 0x7fffu) + 1u : (pos ? 1u : 0u);
+            const uint32_t g    = dst[pos - back];
+            by[u][k] = ext ? g : v & 0xffu;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const uint32_t i = base + 256u * u;
+          if (i + 4 <= total_out) {
+            uint32_t w = by[u][0] | (by[u][1] << 8) | (by[u][2] << 16) | (by[u][3] << 24);
+            __builtin_memcpy(dst + pos + i, &w, 4);
+          } else {
+            for (uint32_t k = 0; k < 4 && i + k < total_out; k++) dst[pos + i + k] = (uint8_t)by[u][k];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      PROF_MARK(7);
+      pos += total_out;
+      a += nch;
+    }
+
+    B    = wave_read(sc.exit, nact - 1u);
+    done = first_stop < 64;                          // the end-of-block code has been consumed
   }
   PROF_FLUSH;
   pos_io = pos;
@@ -1331,7 +1410,7 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
 // MODE 2: second pass: only streams marked INFL_STATUS_DEFERRED are decoded.
 // MODE 3: like MODE 1, but a whole wavefront decodes each Huffman block in parallel (T = 64).
 template <int T, class F, int MODE>
-__global__ __launch_bounds__(64) void infl_batch_kernel(const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const uint8_t *__restrict__ src,
                                                         const uint64_t *__restrict__ src_off,
                                                         uint8_t *__restrict__ dst,
                                                         const uint64_t *__restrict__ dst_off,

@@ -48,6 +48,7 @@ void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 #define __ballot(p) emu::ballot(p)
 #define __popcll(x) __builtin_popcountll(x)
 #define __builtin_amdgcn_ds_bpermute(a, v) emu::bpermute(a, v)
+#define __builtin_amdgcn_readlane(v, l) emu::bpermute((int)((l) << 2), (int)(v))
 
 static inline uint32_t __brev(uint32_t v) {
   v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);

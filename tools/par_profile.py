@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import workloads as wl  # noqa: E402
 
-PHASES = ["stage-in", "first scan", "fix-up", "place", "emit", "fetch-ext", "jump", "write-out"]
+PHASES = ["stage-in", "first scan", "fix-up", "place", "emit", "expand", "jump", "fetch+write"]
 
 
 def main():
@@ -45,14 +45,14 @@ def main():
     v = np.array(list(buf), dtype=np.float64)
     _, status, outlen, _ = b.results(want_dst=False)
     assert (status == 0).all()
-    tot = v[:8].sum()
+    tot = v[:10].sum()
     n = len(comps)
     print("streams %d; wave cycles per stream %.0f" % (n, tot / n))
     for k, name in enumerate(PHASES):
         print("  %-11s %6.2f %%  %9.0f cycles/stream" % (name, 100 * v[k] / tot, v[k] / n))
-    rounds = v[8]
+    rounds = v[10]
     print("rounds/stream %.2f; rescans/round %.2f; sweeps/round %.2f; lanes/round %.1f"
-          % (rounds / n, v[9] / rounds, v[10] / rounds, v[11] / rounds))
+          % (rounds / n, v[11] / rounds, v[12] / rounds, v[13] / rounds))
 
 
 if __name__ == "__main__":
