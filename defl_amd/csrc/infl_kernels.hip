@@ -861,29 +861,27 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
 #endif
 constexpr int      PAR_S        = DEFL_PAR_S;        // sub-sequence length in bits
 constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per round (LDS links)
-constexpr int      PAR_IN       = 2 * PAR_S + 8;     // staged input words: 64 * PAR_S bits + slack
+constexpr int      PAR_IN       = 2 * PAR_S + 4;     // staged input words: 64 * PAR_S bits + 4 for the last column
 constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane stops scanning beyond this many bytes
 constexpr int      PAR_U        = 8;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
-// Staged input words are stored transposed: lane l mostly reads words l * PAR_G + k, so word w
-// lives at (w % PAR_G) * PAR_ROW + w / PAR_G and lanes at the same depth k hit distinct banks.
-constexpr int PAR_G   = PAR_S / 32;
-constexpr int PAR_ROW = ((PAR_IN + PAR_G - 1) / PAR_G) | 1;
-static_assert((PAR_G & (PAR_G - 1)) == 0, "sub-sequence length is a power of two");
+// Staged input words, one column per sub-sequence: row k of column l holds word l * PAR_G + k
+// of the round, for k up to PAR_G + 3, i.e. a column repeats the first four words of the next
+// one.  A lane walking sub-sequence l (it may run up to 48 bits over its end) finds the two
+// words around any of its bit positions at a fixed distance from each other, and lanes at
+// the same depth read neighbouring banks.
+constexpr int PAR_G    = PAR_S / 32;
+constexpr int PAR_ROWS = PAR_G + 4;
+static_assert((PAR_G & (PAR_G - 1)) == 0 && PAR_G >= 4, "sub-sequence length is a power of two >= 128");
 
 #ifndef DEFL_PAR_PAD
 #define DEFL_PAR_PAD 0                               // experiments: extra LDS per wave (lowers occupancy)
 #endif
 struct alignas(16) ParLds {
-  uint32_t in[PAR_G * PAR_ROW];
+  uint32_t in[PAR_ROWS * 64];
   uint16_t link[PAR_R + 8 + DEFL_PAR_PAD / 2];       // 8: slack for whole-word reads at the end
 };
-__device__ __forceinline__ uint32_t par_in_at(uint32_t w) {
-  return (w & (uint32_t)(PAR_G - 1)) * (uint32_t)PAR_ROW + w / (uint32_t)PAR_G;
-}
-static_assert(PAR_LANE_CAP + 258 <= PAR_R, "lane 0 always fits a round");
-static_assert(PAR_R <= 0x4000, "internal links are 14-bit indices");
 
 // Optional cycle accounting of the phases (diagnostic builds only: make prof).
 #ifdef DEFL_PAR_PROFILE
@@ -901,8 +899,8 @@ __device__ unsigned long long g_par_prof[16];
 #endif
 
 struct ParCtx {
-  const uint32_t *in;
-  uint32_t        inbase;        // bit position of in[0]
+  const uint32_t *col;           // the lane's column of staged words (row stride 64)
+  uint32_t        colbit;        // bit position of the column's first word
   uint32_t        total_bits;    // stream length in bits
   const uint16_t *lit, *dist;
 };
@@ -911,71 +909,56 @@ __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
 }
 
-// Per-lane decoder state over the staged input words: 33..64 valid bits in a register pair
-// and the following word already loaded, so a table lookup never waits for an input read.
-// One step decodes ONE code: a literal/length code (ph = 0) or, after a length code, the
-// distance code (ph = 1).  The step is straight-line code (selects, no divergent branches):
-// all 64 lanes run it together whatever kind of code each of them meets.
+// 32 bits of the stream from bit position p on (p inside the column, see ParLds)
+__device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t p) {
+  const uint32_t rel = p - c.colbit, k = (rel >> 5) * 64u;
+  return __builtin_amdgcn_alignbit(c.col[k + 64u], c.col[k], rel);
+}
+
+// Per-lane decoder state.  One step decodes ONE code: a literal/length code (ph = 0) or,
+// after a length code, the distance code (ph = 1).  The step is straight-line code (selects,
+// no divergent branches but the rare second-level table): all 64 lanes run it together
+// whatever kind of code each of them meets.
 struct ParLane {
-  uint64_t buf;
-  uint32_t cnt, nw, widx, p;     // valid bits, prefetched word, index of the word after it, bit position
-  uint32_t ph, o, st;            // phase, bytes produced, stop reason (0 none, 1 end of block, 2 malformed)
+  uint32_t p, ph, o, st;         // bit position, phase, bytes produced, stop (0 none, 1 end of block, 2 malformed)
 };
 
-__device__ __forceinline__ void pl_init(ParLane &b, const ParCtx &c, uint32_t p) {
-  uint32_t rel = p - c.inbase, w = rel >> 5, s = rel & 31u;
-  b.buf  = (((uint64_t)c.in[par_in_at(w + 1)] << 32) | c.in[par_in_at(w)]) >> s;
-  b.cnt  = 64u - s;
-  b.nw   = c.in[par_in_at(w + 2)];
-  b.widx = w + 3;
-  b.p    = p;
-  b.ph   = 0;
-  b.o    = 0;
-  b.st   = 0;
+__device__ __forceinline__ void pl_init(ParLane &b, uint32_t p, uint32_t o) {
+  b.p  = p;
+  b.ph = 0;
+  b.o  = o;
+  b.st = 0;
 }
 
 // Decodes the code at the lane's position.  `value`: literal byte, match length or distance - 1.
 // Returns the entry kind: 1 = literal, 2 = end of block, 3 = length, 4 = distance, 0 = malformed.
+// COUNT = false leaves out the byte count (the first scan only looks for where a chain ends).
+template <bool COUNT>
 __device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_t &value) {
   typedef CompactFmt F;
-  // refill to >= 33 bits (a code and its extra bits take at most 28)
-  const bool     need = r.cnt <= 32u;
-  const uint64_t add  = (uint64_t)r.nw << (r.cnt & 63u);
-  const uint32_t nxt  = c.in[par_in_at(r.widx)];
-  r.buf |= need ? add : 0ull;
-  r.cnt += need ? 32u : 0u;
-  r.nw = need ? nxt : r.nw;
-  r.widx += need ? 1u : 0u;
-
-  const uint32_t  b     = (uint32_t)r.buf;
-  const uint32_t  mbits = r.ph ? (uint32_t)F::DIST_BITS : (uint32_t)F::LIT_BITS;
-  const uint16_t *tab   = r.ph ? c.dist : c.lit;
+  const uint32_t  b     = par_peek(c, r.p);
+  const bool      isd   = r.ph != 0;
+  const uint32_t  mbits = isd ? (uint32_t)F::DIST_BITS : (uint32_t)F::LIT_BITS;
+  const uint16_t *tab   = isd ? c.dist : c.lit;
   uint32_t        e     = tab[b & ((1u << mbits) - 1u)];
   if (e & F::F_SUB)                                  // second-level table (skipped when no lane needs it)
     e = tab[F::sub_at(e) + ((b >> mbits) & ((1u << (e & 15u)) - 1u))];
   const uint32_t cl     = e & 15u;
-  const bool     islit  = (e & F::F_LITERAL) != 0;
-  const bool     isbase = !islit && (e & F::F_BASE) != 0;
+  const uint32_t top    = e >> 14;                   // 2 = literal, 1 = base + extra bits, 0 = end of block / nothing
+  const bool     islit  = top == 2u;
+  const bool     isbase = top == 1u;
   const uint32_t x      = isbase ? (e >> 4) & 15u : 0u;
-  const uint32_t extra  = (b >> cl) & ((1u << x) - 1u);
-  const uint32_t mant   = (((e >> 8) & 7u) << x) + extra;
-  const uint32_t n      = cl + x;
-  r.buf >>= n;
-  r.cnt -= n;
-  r.p += n;
-
-  uint32_t kind;
-  if (r.ph) {
-    kind  = isbase ? 4u : 0u;
-    value = mant;                                    // distance - 1
-    r.ph  = 0;
-  } else {
-    const uint32_t len = (e & F::F_L258) ? 258u : 3u + mant;
-    kind  = islit ? 1u : isbase ? 3u : (e ? 2u : 0u);
-    value = islit ? (e >> 4) & 0xffu : len;
-    r.o += islit ? 1u : isbase ? len : 0u;
-    r.ph = isbase ? 1u : 0u;
+  r.p += cl + x;
+  // literal/length table: top 2 -> literal, 1 -> length, 0 -> end of block unless e == 0
+  uint32_t kind = isd ? (isbase ? 4u : 0u) : (e == 0 ? 0u : islit ? 1u : isbase ? 3u : 2u);
+  if (COUNT) {
+    const uint32_t extra = (b >> cl) & ((1u << x) - 1u);
+    const uint32_t mant  = (((e >> 8) & 7u) << x) + extra;
+    const uint32_t len   = (e & F::F_L258) ? 258u : 3u + mant;
+    value = isd ? mant : islit ? (e >> 4) & 0xffu : len;
+    r.o += isd ? 0u : islit ? 1u : isbase ? len : 0u;
   }
+  r.ph = (!isd && isbase) ? 1u : 0u;
   if (r.p > c.total_bits) kind = 0;                  // would need bits past the end of the stream
   r.st = kind == 0 ? 2u : kind == 2 ? 1u : 0u;
   return kind;
@@ -986,42 +969,52 @@ __device__ __forceinline__ bool pl_more(const ParLane &r, uint32_t limit) {
   return !r.st && (r.ph || (r.p < limit && r.o < PAR_LANE_CAP));
 }
 
-// Result of scanning one sub-sequence.  ck[k-1] (k = 1..3) packs the chain's state at its
-// first symbol boundary at or behind quarter k of the sub-sequence, so that four lanes can
-// later re-walk one chain: (bit position - round start) << 11 | bytes produced so far.
+// Result of scanning one sub-sequence.  ck[k-1] (k = 1..3) packs the chain's state at a symbol
+// boundary after about k quarters of its steps, so that four lanes can later re-walk one
+// chain: (bit position - round start) << 11 | bytes produced so far; 0 = not reached.
 struct ParScan {
-  uint32_t exit, nout, stop;     // stop: 0 = left the sub-sequence (or hit the byte cap), 1 = end of block, 2 = malformed
+  uint32_t exit, nout, stop;     // stop: 0 = left the sub-sequence, 1 = end of block, 2 = malformed, 3 = byte cap
   uint32_t ck[3];
 };
-constexpr int PAR_Q = PAR_S / 4;                     // bits per quarter
-static_assert(PAR_Q >= 48, "a symbol (48 bits at most) never skips a quarter");
-static_assert(PAR_LANE_CAP + 258 < (1u << 11) && 64 * PAR_S + 64 < (1 << 15), "checkpoint packing");
+static_assert(PAR_LANE_CAP + 258 < (1u << 11) && 64 * PAR_S + 64 < (1 << 21), "checkpoint packing");
 
-__device__ __forceinline__ void par_scan(const ParCtx &c, uint32_t round0, uint32_t nominal,
-                                         uint32_t start, ParScan &s) {
+// Scans the sub-sequences of the lanes with `enable` (all lanes must call: the loop is kept
+// wave-uniform so that the step counter stays scalar and taking a checkpoint is a uniform
+// branch).  `quarter`: steps between checkpoints; a lane inside a match at that step takes its
+// checkpoint one step later.  Returns the number of steps of the longest-running lane.
+template <bool FULL>
+__device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint32_t round0,
+                                             uint32_t start, uint32_t limit, uint32_t quarter,
+                                             ParScan &s) {
   ParLane  r;
-  uint32_t k = 1, nb = nominal + PAR_Q;              // next checkpoint and its bit position
-  const uint32_t limit = nominal + PAR_S;
-  s.ck[0] = s.ck[1] = s.ck[2] = 0;
-  pl_init(r, c, start);
-  while (pl_more(r, limit)) {
-    uint32_t value;
-    pl_step(r, c, value);
-    const bool     hit = !r.ph && r.p >= nb && k <= 3;
-    const uint32_t pk  = ((r.p - round0) << 11) | r.o;
-    s.ck[0] = hit && k == 1 ? pk : s.ck[0];
-    s.ck[1] = hit && k == 2 ? pk : s.ck[1];
-    s.ck[2] = hit && k == 3 ? pk : s.ck[2];
-    k += hit ? 1u : 0u;
-    nb += hit ? (uint32_t)PAR_Q : 0u;
+  uint32_t it = 0, ck0 = 0, ck1 = 0, ck2 = 0;
+  pl_init(r, start, 0);
+  for (;;) {
+    const bool more = enable && pl_more(r, limit);
+    if (!__ballot(more)) break;
+    if (more) {
+      uint32_t value;
+      pl_step<FULL>(r, c, value);
+    }
+    it++;
+    if (FULL) {
+      const uint32_t pk   = ((r.p - round0) << 11) | r.o;
+      const bool     take = more && !r.ph;
+      if (it == quarter || it == quarter + 1u) ck0 = (take && !ck0) ? pk : ck0;
+      if (it == 2u * quarter || it == 2u * quarter + 1u) ck1 = (take && !ck1) ? pk : ck1;
+      if (it == 3u * quarter || it == 3u * quarter + 1u) ck2 = (take && !ck2) ? pk : ck2;
+    }
   }
-  const uint32_t fin = ((r.p - round0) << 11) | r.o; // quarters the chain never reached are empty
-  s.ck[0] = k <= 1 ? fin : s.ck[0];
-  s.ck[1] = k <= 2 ? fin : s.ck[1];
-  s.ck[2] = k <= 3 ? fin : s.ck[2];
-  s.exit = r.p;
-  s.nout = r.o;
-  s.stop = r.st;
+  if (enable) {
+    const uint32_t fin = ((r.p - round0) << 11) | r.o;   // quarters the chain never reached are empty
+    s.ck[0] = ck0 ? ck0 : fin;
+    s.ck[1] = ck1 ? ck1 : fin;
+    s.ck[2] = ck2 ? ck2 : fin;
+    s.exit  = r.p;
+    s.nout  = r.o;
+    s.stop  = r.st ? r.st : (r.p < limit ? 3u : 0u); // still inside the sub-sequence: the byte cap
+  }
+  return it;
 }
 
 __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
@@ -1032,6 +1025,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
   const uint32_t total_bits = r.ilen * 8u;
   uint32_t       guard      = total_bits + 8u;       // every round consumes at least one bit
   bool           done       = false;
+  uint32_t       quarter    = 10;                    // steps per quarter of a chain, adapted per round
   PROF_DECL;
 
   while (!done) {
@@ -1048,42 +1042,53 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       uint32_t q   = off < r.ilen4 ? off : r.ilen4;
       uint32_t raw;
       __builtin_memcpy(&raw, r.src + q, 4);
-      uint32_t d = off - q;
-      if (w < (uint32_t)PAR_IN) P.in[par_in_at(w)] = d >= 4 ? 0u : raw >> (8u * d);
+      uint32_t d   = off - q;
+      uint32_t val = d >= 4 ? 0u : raw >> (8u * d);
+      uint32_t k = w & (uint32_t)(PAR_G - 1), col = w / (uint32_t)PAR_G;
+      if (col < 64u) P.in[k * 64u + col] = val;
+      if (k < 4u && col >= 1u && col <= 64u) P.in[(k + (uint32_t)PAR_G) * 64u + col - 1u] = val;
     }
     group_sync();
     PROF_MARK(0);
     ParCtx c;
-    c.in         = P.in;
-    c.inbase     = inbyte * 8u;
+    c.col        = P.in + lane;
+    c.colbit     = inbyte * 8u + (uint32_t)lane * PAR_S;
     c.total_bits = total_bits;
     c.lit        = lit;
     c.dist       = dist;
 
     // 1. scan, 2. fix up
-    const uint32_t nominal = B + (uint32_t)lane * PAR_S;
-    uint32_t       start   = nominal;
+    const uint32_t limit = B + (uint32_t)(lane + 1) * PAR_S;
+    uint32_t       start = B + (uint32_t)lane * PAR_S;
     ParScan        sc;
-    par_scan(c, B, nominal, start, sc);
+    {
+      // lane 0 starts on the true chain; the other lanes only learn where a chain that starts
+      // at their guess ends (no byte counts, no checkpoints)
+      const uint32_t steps = par_scan<false>(c, true, B, start, limit, quarter, sc);
+      const uint32_t q4    = (steps + 3u) / 4u;      // the full scans aim their checkpoints at these
+      quarter = q4 < 4u ? 4u : q4;
+    }
     PROF_MARK(1);
-    for (int iter = 0; iter < 64; iter++) {
+    bool counted = false;
+    for (int iter = 0; iter < 65; iter++) {
       uint32_t pe       = wave_read(sc.exit, lane ? lane - 1 : 0);
       uint64_t stopmask = __ballot(sc.stop != 0);
       bool     dead     = (stopmask & ((1ull << lane) - 1ull)) != 0;   // behind the end of the block
-      bool     changed  = lane > 0 && !dead && pe != start;
+      bool     changed  = !dead && ((lane > 0 && pe != start) || !counted);   // every lane: one full scan at least
       if (!__ballot(changed)) break;
       PROF_COUNT(1, 1);
-      if (changed) {
-        start = pe;
-        par_scan(c, B, nominal, start, sc);
-      }
+      start   = changed && lane > 0 ? pe : start;
+      counted = counted || changed;
+      par_scan<true>(c, changed, B, start, limit, quarter, sc);
     }
 
     PROF_MARK(2);
-    // 3. place: lanes up to the one that met the end of the block hold the true chain
+    // 3. place: lanes up to the first one that stopped inside its sub-sequence hold the true
+    //    chain (the lanes behind it never learnt where to start: they wait for the next round)
     const uint64_t stopmask   = __ballot(sc.stop != 0);
     const uint32_t first_stop = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : 64u;
-    if (first_stop < 64 && wave_read(sc.stop, first_stop) == 2) return false;   // malformed on the true chain
+    const uint32_t why        = first_stop < 64 ? wave_read(sc.stop, first_stop) : 0u;
+    if (why == 2) return false;                      // malformed on the true chain
     const uint32_t nact = first_stop < 64 ? first_stop + 1u : 64u;
     uint32_t       cum  = (uint32_t)lane < nact ? sc.nout : 0;
     for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
@@ -1125,16 +1130,18 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
         const uint32_t pb = q ? B + (kb >> 11) : cs;
         const uint32_t pe = q < 3 ? B + (ke >> 11) : ce;
         ParLane  rl;
+        ParCtx   cq  = c;                            // the chain's column instead of the lane's own
         uint32_t oh  = 0;
         bool     act = ch < a + nch && pb < pe;
+        cq.col    = P.in + chl;
+        cq.colbit = inbyte * 8u + chl * PAR_S;
         group_sync();
-        pl_init(rl, c, act ? pb : B);
-        rl.o = q ? kb & 0x7ffu : 0u;
+        pl_init(rl, act ? pb : B + chl * PAR_S, q ? kb & 0x7ffu : 0u);
         while (__ballot(act)) {
           if (act) {
             uint32_t       value;
             const uint32_t at   = o0 + rl.o;
-            const uint32_t kind = pl_step(rl, c, value);
+            const uint32_t kind = pl_step<true>(rl, cq, value);
             if (kind == 1) P.link[at] = (uint16_t)(LK_LIT | value);
             if (kind == 3) oh = at;
             if (kind == 4) {
@@ -1219,33 +1226,25 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       }
       PROF_MARK(6);
 
-      // 5c. write out, four bytes per lane and pass: literals from the links, the others from
-      //     the output before the group (two passes' loads in flight together)
-      for (uint32_t base = (uint32_t)lane * 4u; base < total_out + (uint32_t)lane * 4u; base += 512) {
-        uint32_t by[2][4];
+      // 5c. write out, one byte per lane and access (neighbouring lanes, neighbouring bytes:
+      //     the stores and most of the loads of bytes from before the group coalesce)
+      for (uint32_t base = (uint32_t)lane; base < total_out + (uint32_t)lane; base += 64 * PAR_U) {
+        uint32_t v[PAR_U], g[PAR_U];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const uint32_t i = base + 256u * u;
-          uint64_t       q;
-          __builtin_memcpy(&q, &P.link[i < total_out ? i : 0u], 8);   // up to 3 entries of slack behind
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const uint32_t v    = (uint32_t)(q >> (16 * k)) & 0xffffu;
-            const bool     ext  = (v & LK_EXT) && i + k < total_out;
-            const uint32_t back = ext ? (v & 0x7fffu) + 1u : (pos ? 1u : 0u);
-            const uint32_t g    = dst[pos - back];
-            by[u][k] = ext ? g : v & 0xffu;
-          }
+        for (int u = 0; u < PAR_U; u++) {
+          const uint32_t i = base + 64u * u;
+          v[u] = P.link[i < total_out ? i : 0u];
+          v[u] = i < total_out ? v[u] : LK_LIT;
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const uint32_t i = base + 256u * u;
-          if (i + 4 <= total_out) {
-            uint32_t w = by[u][0] | (by[u][1] << 8) | (by[u][2] << 16) | (by[u][3] << 24);
-            __builtin_memcpy(dst + pos + i, &w, 4);
-          } else {
-            for (uint32_t k = 0; k < 4 && i + k < total_out; k++) dst[pos + i + k] = (uint8_t)by[u][k];
-          }
+        for (int u = 0; u < PAR_U; u++) {
+          const uint32_t back = (v[u] & LK_EXT) ? (v[u] & 0x7fffu) + 1u : (pos ? 1u : 0u);
+          g[u] = dst[pos - back];
+        }
+#pragma unroll
+        for (int u = 0; u < PAR_U; u++) {
+          const uint32_t i = base + 64u * u;
+          if (i < total_out) dst[pos + i] = (uint8_t)((v[u] & LK_EXT) ? g[u] : v[u]);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1255,7 +1254,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     }
 
     B    = wave_read(sc.exit, nact - 1u);
-    done = first_stop < 64;                          // the end-of-block code has been consumed
+    done = why == 1;                                 // the end-of-block code has been consumed
   }
   PROF_FLUSH;
   pos_io = pos;

@@ -48,6 +48,9 @@ void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 #define __ballot(p) emu::ballot(p)
 #define __popcll(x) __builtin_popcountll(x)
 #define __builtin_amdgcn_ds_bpermute(a, v) emu::bpermute(a, v)
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
+}
 #define __builtin_amdgcn_readlane(v, l) emu::bpermute((int)((l) << 2), (int)(v))
 
 static inline uint32_t __brev(uint32_t v) {
