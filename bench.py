@@ -88,7 +88,7 @@ def main():
                     help="distinct streams generated per GPU; the batch tiles them into distinct "
                          "source and destination slots")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("DEFL_BENCH_LANES", 16)))
-    ap.add_argument("--variant", type=int, default=int(os.environ.get("DEFL_BENCH_VARIANT", 1)),
+    ap.add_argument("--variant", type=int, default=int(os.environ.get("DEFL_BENCH_VARIANT", 2)),
                     help="0 = tables in the reference geometry, 1 = compact tables + deferred pass, "
                          "2 = wavefront-parallel block decode + deferred pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")

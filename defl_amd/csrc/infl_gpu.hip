@@ -18,7 +18,7 @@ namespace {
 
 std::mutex g_mu;            // guards the cached workspace below
 int        g_lanes = 16;    // lanes of a wavefront per stream
-int        g_variant = 1;   // 0 reference-geometry tables, 1 compact tables + deferred pass
+int        g_variant = 2;   // 0 reference-geometry tables, 1 compact tables + deferred pass, 2 parallel first
 
 struct Buf {
   void  *p   = nullptr;

@@ -863,6 +863,7 @@ constexpr int      PAR_S        = DEFL_PAR_S;        // sub-sequence length in b
 constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per round (LDS links)
 constexpr int      PAR_IN       = 2 * PAR_S + 4;     // staged input words: 64 * PAR_S bits + 4 for the last column
 constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane stops scanning beyond this many bytes
+constexpr int      PAR_MAX_FIXUP = 10;               // rescans per round before the stream is handed to the serial passes
 constexpr int      PAR_U        = 8;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
@@ -1076,6 +1077,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       bool     dead     = (stopmask & ((1ull << lane) - 1ull)) != 0;   // behind the end of the block
       bool     changed  = !dead && ((lane > 0 && pe != start) || !counted);   // every lane: one full scan at least
       if (!__ballot(changed)) break;
+      if (iter > PAR_MAX_FIXUP) return false;        // codes that do not re-synchronise: serial passes
       PROF_COUNT(1, 1);
       start   = changed && lane > 0 ? pe : start;
       counted = counted || changed;
@@ -1089,6 +1091,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     const uint32_t first_stop = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : 64u;
     const uint32_t why        = first_stop < 64 ? wave_read(sc.stop, first_stop) : 0u;
     if (why == 2) return false;                      // malformed on the true chain
+    if (why == 3 && first_stop < 8) return false;    // very long matches: the serial copy loops do better
     const uint32_t nact = first_stop < 64 ? first_stop + 1u : 64u;
     uint32_t       cum  = (uint32_t)lane < nact ? sc.nout : 0;
     for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
@@ -1408,6 +1411,7 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
 //         its result; any other stream is marked INFL_STATUS_DEFERRED.
 // MODE 2: second pass: only streams marked INFL_STATUS_DEFERRED are decoded.
 // MODE 3: like MODE 1, but a whole wavefront decodes each Huffman block in parallel (T = 64).
+// MODE 4: like MODE 1, but only for streams marked INFL_STATUS_DEFERRED (by MODE 3).
 template <int T, class F, int MODE>
 __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const uint8_t *__restrict__ src,
                                                         const uint64_t *__restrict__ src_off,
@@ -1419,7 +1423,7 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
                                                         int32_t *__restrict__ detail,
                                                         uint32_t *__restrict__ inpos) {
   constexpr int  G    = 64 / T;                    // streams per wavefront
-  constexpr int  SYM  = MODE == 1 ? 1 : MODE == 3 ? 2 : 0;
+  constexpr int  SYM  = (MODE == 1 || MODE == 4) ? 1 : MODE == 3 ? 2 : 0;
   static_assert(MODE != 3 || T == 64, "the parallel block decoder uses the whole wavefront");
   __shared__ StreamLds<F> lds[G];
   ParLds *parp = nullptr;
@@ -1435,7 +1439,7 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
   const uint64_t i      = (uint64_t)blockIdx.x * G + group;
 
   if (i >= n) return;
-  if (MODE == 2 && status[i] != INFL_STATUS_DEFERRED) return;
+  if ((MODE == 2 || MODE == 4) && status[i] != INFL_STATUS_DEFERRED) return;
 
   const uint64_t s0 = src_off[i], s1 = src_off[i + 1];
   const uint64_t d0 = dst_off[i], d1 = dst_off[i + 1];
@@ -1452,7 +1456,7 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
                                          (uint32_t)(d1 - d0), (flags & 0xff) == 1, lds[group],
                                          nullptr, lig, gshift, out, pos, cur);
   if (lig == 0) {
-    if ((MODE == 1 || MODE == 3) && rc != INFL_D_OK) {
+    if ((MODE == 1 || MODE == 3 || MODE == 4) && rc != INFL_D_OK) {
       status[i] = INFL_STATUS_DEFERRED;
       return;
     }
@@ -1467,8 +1471,9 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
 
 // variant 0: reference-geometry tables only (one launch).
 // variant 1: compact tables first, reference-geometry tables for what they defer (two launches).
-// variant 2: wavefront-parallel block decode first (one wavefront per stream), then as variant 1
-//            for what it defers.
+// variant 2: wavefront-parallel block decode first (one wavefront per stream); what it defers
+//            (data whose codes re-synchronise badly, very long matches, anything unusual) goes
+//            through the two serial passes of variant 1 (three launches).
 // variant 3: diagnostic: the parallel pass alone; deferred streams keep INFL_STATUS_DEFERRED.
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
@@ -1490,7 +1495,10 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
     LAUNCH(T, RefFmt, 2);       \
   } else {                      \
     LAUNCH(64, CompactFmt, 3);  \
-    if (variant == 2) LAUNCH(T, RefFmt, 2); \
+    if (variant == 2) {         \
+      LAUNCH(T, CompactFmt, 4); \
+      LAUNCH(T, RefFmt, 2);     \
+    }                           \
   }
   switch (lanes) {
     case 64: LAUNCH_T(64) break;

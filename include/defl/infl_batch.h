@@ -98,16 +98,23 @@ UNZ_EXPORT int   infl_gpu_download(void *host_dst, const void *dev_src, size_t b
 UNZ_EXPORT int   infl_gpu_sync(void);
 
 /* Tuning knob for measurements: lanes of a wavefront that cooperate on one
-   stream (64, 32, 16 or 8).  Returns the value in effect. */
+   stream in the serial passes (64, 32, 16 or 8).  Returns the value in effect. */
 UNZ_EXPORT int
 infl_gpu_set_lanes_per_stream(int lanes);
 
-/* Tuning knob for measurements: 0 = one launch with decode tables in the
-   reference's geometry (32-bit entries, 10 KiB of LDS per stream); 1 = a first
-   launch with compact 16-bit tables (2.7 KiB per stream, four times the streams
-   in flight) plus a second launch in the reference's geometry for the streams
-   the first one could not finish.  Results are identical.  Returns the value
-   in effect. */
+/* Tuning knob for measurements.  Results are identical for every value.
+   0 = one launch, symbols decoded one after the other per stream, decode
+       tables in the reference's geometry (32-bit entries, 10 KiB of LDS per
+       stream);
+   1 = a first launch with compact 16-bit tables (2.7 KiB per stream, four
+       times the streams in flight) plus a second launch as 0 for the streams
+       the first one could not finish;
+   2 = (default) a first launch in which a whole wavefront decodes each
+       Huffman block in parallel (64 speculative sub-sequences that
+       re-synchronise, matches resolved in LDS), then the two launches of 1 for
+       the streams it hands over: codes that do not re-synchronise, runs of
+       very long matches, anything malformed.
+   Returns the value in effect. */
 UNZ_EXPORT int
 infl_gpu_set_table_variant(int variant);
 

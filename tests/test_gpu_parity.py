@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DATA = os.path.join(HERE, "golden", "defl_testdata")
 ALL = sorted(os.listdir(os.path.join(DATA, "compressed")))
 PAIRS = [f for f in ALL if os.path.exists(os.path.join(DATA, "raw", f))]
-DEFAULT_VARIANT = 1
+DEFAULT_VARIANT = 2
 VARIANTS = [(64, 0), (32, 0), (16, 0), (8, 0), (64, 1), (32, 1), (16, 1), (8, 1), (16, 2), (64, 2)]
 
 

@@ -68,12 +68,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="stored,fixed,mixed,png")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
     import torch  # noqa: F401  (same HIP runtime for the engine)
     from defl_amd import capi
     from tests import oracle_lib
     eng, oracle = capi.load(), oracle_lib.load()
     assert eng.lib.infl_gpu_init(0) == 0
+    if args.variant >= 0:
+        eng.lib.infl_gpu_set_table_variant(args.variant)
     which = args.which.split(",")
     if "stored" in which:
         pairs = [wl.stored_stream(i, 65536) for i in range(256)]
@@ -91,6 +94,25 @@ def main():
         comps = [wl.deflate(x) for x in raws]
         r = run_device(eng, oracle, comps, [len(x) for x in raws], 1, 5, int(64 * args.scale))
         print(json.dumps({"config": "mixed sizes 1 KiB..256 KiB (log-uniform), sorted descending", **r}), flush=True)
+    if "runs" in which:
+        # very compressible: long runs and repeats (matches of length 258, distance 1 and far)
+        rng = np.random.default_rng(7)
+        raws = []
+        for i in range(64):
+            parts = []
+            while sum(len(x) for x in parts) < 65536:
+                parts.append(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 4000)))
+            raws.append(b"".join(parts)[:65536])
+        comps = [wl.deflate(x) for x in raws]
+        r = run_device(eng, oracle, comps, [65536] * 64, 1, 5, int(1024 * args.scale))
+        print(json.dumps({"config": "byte runs (ratio %.4f)" % (sum(map(len, comps)) / (64 * 65536.0)), **r}), flush=True)
+    if "noisy" in which:
+        # barely compressible: 6 random bits per byte, almost all literals with ~6-bit codes
+        rng = np.random.default_rng(8)
+        raws = [bytes(rng.integers(32, 96, 65536, dtype=np.uint8)) for i in range(64)]
+        comps = [wl.deflate(x) for x in raws]
+        r = run_device(eng, oracle, comps, [65536] * 64, 1, 5, int(1024 * args.scale))
+        print(json.dumps({"config": "6-bit noise (ratio %.4f)" % (sum(map(len, comps)) / (64 * 65536.0)), **r}), flush=True)
     if "png" in which:
         n = int(4096 * args.scale)
         raws = [wl.png_like(i % 256) for i in range(n)]
