@@ -919,16 +919,20 @@ __device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t p) {
 // Per-lane decoder state.  One step decodes ONE code: a literal/length code (ph = 0) or,
 // after a length code, the distance code (ph = 1).  The step is straight-line code (selects,
 // no divergent branches but the rare second-level table): all 64 lanes run it together
-// whatever kind of code each of them meets.
+// whatever kind of code each of them meets.  A lane goes on while p < lim: lim is the end of
+// its stretch, everything while it is inside a match, nothing once it has stopped.
 struct ParLane {
   uint32_t p, ph, o, st;         // bit position, phase, bytes produced, stop (0 none, 1 end of block, 2 malformed)
+  uint32_t lim, limit;
 };
 
-__device__ __forceinline__ void pl_init(ParLane &b, uint32_t p, uint32_t o) {
-  b.p  = p;
-  b.ph = 0;
-  b.o  = o;
-  b.st = 0;
+__device__ __forceinline__ void pl_init(ParLane &b, uint32_t p, uint32_t o, uint32_t limit, bool enable) {
+  b.p     = p;
+  b.ph    = 0;
+  b.o     = o;
+  b.st    = 0;
+  b.limit = limit;
+  b.lim   = enable ? limit : 0u;
 }
 
 // Decodes the code at the lane's position.  `value`: literal byte, match length or distance - 1.
@@ -961,59 +965,68 @@ __device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_
   }
   r.ph = (!isd && isbase) ? 1u : 0u;
   if (r.p > c.total_bits) kind = 0;                  // would need bits past the end of the stream
-  r.st = kind == 0 ? 2u : kind == 2 ? 1u : 0u;
+  const bool stop = kind == 0 || kind == 2;
+  r.st  = kind == 0 ? 2u : kind == 2 ? 1u : 0u;
+  r.lim = stop ? 0u : r.ph ? ~0u : r.limit;
   return kind;
 }
 
-// a lane goes on while it is inside a match, or inside its sub-sequence and under the byte cap
-__device__ __forceinline__ bool pl_more(const ParLane &r, uint32_t limit) {
-  return !r.st && (r.ph || (r.p < limit && r.o < PAR_LANE_CAP));
-}
-
-// Result of scanning one sub-sequence.  ck[k-1] (k = 1..3) packs the chain's state at a symbol
-// boundary after about k quarters of its steps, so that four lanes can later re-walk one
-// chain: (bit position - round start) << 11 | bytes produced so far; 0 = not reached.
+// Result of scanning one sub-sequence.  ck[k-1] (k = 1..3) packs the chain's state at the
+// symbol boundary it had reached after k quarters of the expected number of steps, so that
+// four lanes can later re-walk one chain: (bit position - round start) << 12 | bytes so far.
 struct ParScan {
   uint32_t exit, nout, stop;     // stop: 0 = left the sub-sequence, 1 = end of block, 2 = malformed, 3 = byte cap
   uint32_t ck[3];
 };
-static_assert(PAR_LANE_CAP + 258 < (1u << 11) && 64 * PAR_S + 64 < (1 << 21), "checkpoint packing");
+static_assert(PAR_R < (1u << 12) && 64 * PAR_S + 64 < (1 << 20), "checkpoint packing");
 
-// Scans the sub-sequences of the lanes with `enable` (all lanes must call: the loop is kept
-// wave-uniform so that the step counter stays scalar and taking a checkpoint is a uniform
-// branch).  `quarter`: steps between checkpoints; a lane inside a match at that step takes its
-// checkpoint one step later.  Returns the number of steps of the longest-running lane.
+// Scans the sub-sequences of the lanes with `enable`.  All lanes must call: the loops are kept
+// wave-uniform (`quarter` steps, then a checkpoint for every lane, four times over; the last
+// stretch runs until every lane is through).  Returns the number of steps taken.
 template <bool FULL>
 __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint32_t round0,
                                              uint32_t start, uint32_t limit, uint32_t quarter,
                                              ParScan &s) {
   ParLane  r;
-  uint32_t it = 0, ck0 = 0, ck1 = 0, ck2 = 0;
-  pl_init(r, start, 0);
-  for (;;) {
-    const bool more = enable && pl_more(r, limit);
-    if (!__ballot(more)) break;
-    if (more) {
-      uint32_t value;
-      pl_step<FULL>(r, c, value);
+  uint32_t it = 0, ck[3] = {0u, 0u, 0u};
+  uint32_t sp = start, so = 0;                       // where the symbol a lane is inside began
+  int      nq = 0;
+  bool     all_done = false;
+  pl_init(r, start, 0, limit, enable);
+  for (int q = 0; q < 4 && !all_done; q++) {
+    for (uint32_t k = 0; k < quarter || q == 3; k++) {
+      const bool more = r.p < r.lim;
+      if (!__ballot(more)) {
+        all_done = true;
+        break;
+      }
+      if (more) {
+        uint32_t value;
+        if (FULL) {
+          sp = r.ph ? sp : r.p;
+          so = r.ph ? so : r.o;
+        }
+        pl_step<FULL>(r, c, value);
+      }
+      it++;
     }
-    it++;
-    if (FULL) {
-      const uint32_t pk   = ((r.p - round0) << 11) | r.o;
-      const bool     take = more && !r.ph;
-      if (it == quarter || it == quarter + 1u) ck0 = (take && !ck0) ? pk : ck0;
-      if (it == 2u * quarter || it == 2u * quarter + 1u) ck1 = (take && !ck1) ? pk : ck1;
-      if (it == 3u * quarter || it == 3u * quarter + 1u) ck2 = (take && !ck2) ? pk : ck2;
+    if (FULL && q < 3 && !all_done) {
+      ck[q] = ((((r.ph ? sp : r.p)) - round0) << 12) | (r.ph ? so : r.o);
+      nq    = q + 1;
+      if (!r.ph && r.o >= PAR_LANE_CAP && r.p < r.lim) {   // byte cap: the round ends with this lane
+        r.st  = 3;
+        r.lim = 0;
+      }
     }
   }
   if (enable) {
-    const uint32_t fin = ((r.p - round0) << 11) | r.o;   // quarters the chain never reached are empty
-    s.ck[0] = ck0 ? ck0 : fin;
-    s.ck[1] = ck1 ? ck1 : fin;
-    s.ck[2] = ck2 ? ck2 : fin;
+    const uint32_t fin = ((r.p - round0) << 12) | r.o;   // stretches never begun are empty
+    s.ck[0] = nq > 0 ? ck[0] : fin;
+    s.ck[1] = nq > 1 ? ck[1] : fin;
+    s.ck[2] = nq > 2 ? ck[2] : fin;
     s.exit  = r.p;
     s.nout  = r.o;
-    s.stop  = r.st ? r.st : (r.p < limit ? 3u : 0u); // still inside the sub-sequence: the byte cap
+    s.stop  = r.st;
   }
   return it;
 }
@@ -1130,8 +1143,8 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
         const uint32_t k1 = wave_read(sc.ck[0], chl), k2 = wave_read(sc.ck[1], chl), k3 = wave_read(sc.ck[2], chl);
         const uint32_t kb = q == 1 ? k1 : q == 2 ? k2 : k3;      // state at the quarter's begin
         const uint32_t ke = q == 0 ? k1 : q == 1 ? k2 : k3;      // and at its end
-        const uint32_t pb = q ? B + (kb >> 11) : cs;
-        const uint32_t pe = q < 3 ? B + (ke >> 11) : ce;
+        const uint32_t pb = q ? B + (kb >> 12) : cs;
+        const uint32_t pe = q < 3 ? B + (ke >> 12) : ce;
         ParLane  rl;
         ParCtx   cq  = c;                            // the chain's column instead of the lane's own
         uint32_t oh  = 0;
@@ -1139,19 +1152,21 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
         cq.col    = P.in + chl;
         cq.colbit = inbyte * 8u + chl * PAR_S;
         group_sync();
-        pl_init(rl, act ? pb : B + chl * PAR_S, q ? kb & 0x7ffu : 0u);
-        while (__ballot(act)) {
-          if (act) {
+        pl_init(rl, act ? pb : B + chl * PAR_S, q ? kb & 0xfffu : 0u, pe, act);
+        while (__ballot(rl.p < rl.lim)) {
+          if (rl.p < rl.lim) {
             uint32_t       value;
             const uint32_t at   = o0 + rl.o;
             const uint32_t kind = pl_step<true>(rl, cq, value);
             if (kind == 1) P.link[at] = (uint16_t)(LK_LIT | value);
             if (kind == 3) oh = at;
             if (kind == 4) {
-              if (value >= pos + oh) bad = true;     // distance reaches before the output start
+              if (value >= pos + oh) {               // distance reaches before the output start
+                bad    = true;
+                rl.lim = 0;
+              }
               P.link[oh] = (uint16_t)(LK_EXT | value);
             }
-            act = !bad && !rl.st && (rl.ph || rl.p < pe);
           }
         }
       }

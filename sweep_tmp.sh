@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python3 -u -m pytest tests -x -q --timeout 120 --timeout-method thread -m gpu 2>&1 | tail -3 || exit 1
-timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 || exit 1
-timeout -k 10 400 python3 bench.py 2>gpurun_out/bench_err.log | tee gpurun_out/bench_r01_full.json || exit 1
-timeout -k 10 500 python3 tools/bench_configs.py --which stored,fixed,mixed,runs,noisy,png 2>/dev/null | tee gpurun_out/configs_r01.jsonl | cut -c1-250
+timeout -k 10 400 python3 -u -m pytest tests/test_gpu_parity.py -x -q --timeout 120 --timeout-method thread -m gpu -k "variant or 2 or fuzz" 2>&1 | tail -3 || exit 1
+DEFL_AMD_LIB=$GRAFT_REPO_ROOT/defl_amd/libdefl_amd_prof.so timeout -k 10 200 python3 tools/par_profile.py || exit 1
+timeout -k 10 200 python3 bench.py --steps 5 --warmup 1 --streams 32768 --pool 512 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms'])" || exit 1
