@@ -210,7 +210,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 t = json.load(open(tpath))
-                if t.get("streams") == n and t.get("lanes") == args.lanes:
+                if t.get("streams") == n and t.get("variant", args.variant) == args.variant:
                     traffic = t.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
