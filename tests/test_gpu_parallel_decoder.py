@@ -1,0 +1,100 @@
+"""Parity of the wavefront-parallel block decoder (table variant 2) on the shapes that stress its
+own machinery: block ends at every position of a round, several blocks per stream, chains that hit
+the per-lane byte cap, codes that never re-synchronise, output that fills up inside a round,
+input that ends inside a round.  Everything is compared with the CPU oracle, bit for bit."""
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import workloads as wl
+from tests.test_gpu_parity import _check_batch, _corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _deflate_flushed(raw, rng, level=6):
+    """zlib stream with flush points: empty stored blocks and fresh dynamic blocks in between."""
+    c = zlib.compressobj(level)
+    out, i = [], 0
+    while i < len(raw):
+        n = rng.randint(1, 9000)
+        out.append(c.compress(raw[i:i + n]))
+        out.append(c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK])))
+        i += n
+    out.append(c.flush())
+    return b"".join(out)
+
+
+def test_every_block_length(engine, oracle):
+    rng = random.Random(11)
+    text = _corpus(rng, 60000)
+    raws = [text[:n] for n in list(range(0, 700, 7)) + list(range(700, 60000, 1499))]
+    streams = [wl.deflate(r) for r in raws]
+    _check_batch(engine, oracle, streams, [len(r) for r in raws], 1, 16, "lengths", 2)
+
+
+def test_many_blocks_per_stream(engine, oracle):
+    rng = random.Random(12)
+    raws = [_corpus(rng, rng.randint(1, 150000)) for _ in range(40)]
+    streams = [_deflate_flushed(r, rng, rng.choice([1, 6, 9])) for r in raws]
+    _check_batch(engine, oracle, streams, [len(r) + 5 for r in raws], 1, 16, "flushed", 2)
+
+
+def test_long_matches_hit_the_byte_cap(engine, oracle):
+    rng = random.Random(13)
+    raws = []
+    for _ in range(24):
+        parts = []
+        while sum(map(len, parts)) < 90000:
+            kind = rng.random()
+            if kind < 0.5:
+                parts.append(bytes([rng.randrange(256)]) * rng.randint(1, 5000))
+            elif kind < 0.8:
+                parts.append(_corpus(rng, rng.randint(1, 3000)))
+            else:
+                parts.append(bytes(rng.randrange(256) for _ in range(rng.randint(1, 40))) * rng.randint(1, 300))
+        raws.append(b"".join(parts))
+    streams = [wl.deflate(r, rng.choice([1, 6, 9])) for r in raws]
+    _check_batch(engine, oracle, streams, [len(r) for r in raws], 1, 16, "runs", 2)
+
+
+def test_codes_that_do_not_resynchronise(engine, oracle):
+    rng = np.random.default_rng(14)
+    raws = [bytes(rng.integers(32, 32 + (1 << k), 30000 + 1000 * k, dtype=np.uint8)) for k in (1, 2, 3, 4, 5, 6, 7)]
+    raws += [bytes(rng.integers(0, 256, 20000, dtype=np.uint8))]
+    streams = [wl.deflate(r, 6, True, zlib.Z_HUFFMAN_ONLY) for r in raws] + [wl.deflate(r) for r in raws]
+    streams += [wl.deflate(r, 6, True, zlib.Z_FIXED) for r in raws]
+    _check_batch(engine, oracle, streams, [len(r) for r in raws] * 3, 1, 16, "no-resync", 2)
+
+
+def test_output_fills_up_inside_a_round(engine, oracle):
+    rng = random.Random(15)
+    text = _corpus(rng, 50000)
+    comp = wl.deflate(text)
+    caps = [0, 1, 63, 64, 65, 1000, 2047, 2048, 2049, 6143, 6144, 6145, 20000, 49999, 50000, 50001]
+    _check_batch(engine, oracle, [comp] * len(caps), caps, 1, 16, "caps", 2)
+
+
+def test_input_ends_inside_a_round(engine, oracle):
+    rng = random.Random(16)
+    text = _corpus(rng, 50000)
+    comp = wl.deflate(text)
+    cuts = sorted(set(list(range(0, 64)) + list(range(64, len(comp), 397)) + [len(comp) - k for k in range(1, 12)]))
+    streams = [comp[:k] for k in cuts]
+    _check_batch(engine, oracle, streams, [50000] * len(cuts), 1, 16, "cuts", 2)
+
+
+def test_bit_flips_in_long_streams(engine, oracle):
+    rng = random.Random(17)
+    text = _corpus(rng, 80000)
+    comp = bytearray(wl.deflate(text))
+    streams = []
+    for _ in range(96):
+        m = bytearray(comp)
+        for _ in range(rng.randint(1, 3)):
+            i = rng.randrange(2, len(m))
+            m[i] ^= 1 << rng.randrange(8)
+        streams.append(bytes(m))
+    _check_batch(engine, oracle, streams, [80000] * len(streams), 1, 16, "flips", 2)

@@ -83,3 +83,26 @@ def test_emulated_kernel_zlib_and_fuzz(oracle):
     _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 8, 1)
     _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 64, 2)
     _compare(oracle, bad, [8000] * len(bad), 0, 64, 2)
+
+
+def test_emulated_parallel_decoder_corner_shapes(oracle):
+    """Wavefront-parallel block decoder (variant 2, 64 lanes): several blocks per stream, chains
+    that hit the per-lane byte cap, codes that never re-synchronise, output and input ending
+    inside a round."""
+    rng = random.Random(78)
+    nrng = np.random.default_rng(79)
+    text = wl.text_stream(5, 24000)
+    c = zlib.compressobj(6)
+    flushed = b"".join(c.compress(text[i:i + 3500]) + c.flush(zlib.Z_FULL_FLUSH if i % 7000 else zlib.Z_SYNC_FLUSH)
+                       for i in range(0, len(text), 3500)) + c.flush()
+    runs = b"".join(bytes([rng.randrange(256)]) * rng.randint(1, 3000) for _ in range(12)) + text[:2000]
+    noise = bytes(nrng.integers(32, 96, 9000, dtype=np.uint8))
+    streams = [flushed, wl.deflate(runs), wl.deflate(noise), wl.deflate(noise, 6, True, zlib.Z_HUFFMAN_ONLY),
+               wl.deflate(text, 6, True, zlib.Z_FIXED)]
+    caps = [len(text), len(runs), len(noise), len(noise), len(text)]
+    _compare(oracle, streams, caps, 1, 64, 2)
+    comp = wl.deflate(text)
+    out_caps = [0, 1, 63, 64, 65, 2047, 2048, 2049, 6145, len(text) - 1]
+    _compare(oracle, [comp] * len(out_caps), out_caps, 1, 64, 2)
+    cuts = [1, 2, 7, 8, 9, 40, 300, 301, len(comp) // 2, len(comp) - 5, len(comp) - 1]
+    _compare(oracle, [comp[:k] for k in cuts], [len(text)] * len(cuts), 1, 64, 2)
