@@ -863,7 +863,7 @@ constexpr int      PAR_S        = DEFL_PAR_S;        // sub-sequence length in b
 constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per round (LDS links)
 constexpr int      PAR_IN       = 2 * PAR_S + 4;     // staged input words: 64 * PAR_S bits + 4 for the last column
 constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane stops scanning beyond this many bytes
-constexpr int      PAR_MAX_FIXUP = 10;               // rescans per round before the stream is handed to the serial passes
+constexpr int      PAR_MAX_FIXUP = 8;                // full scans per round before the stream is handed to the serial passes
 constexpr int      PAR_U        = 8;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
@@ -886,16 +886,19 @@ struct alignas(16) ParLds {
 
 // Optional cycle accounting of the phases (diagnostic builds only: make prof).
 #ifdef DEFL_PAR_PROFILE
-__device__ unsigned long long g_par_prof[16];
-#define PROF_DECL      uint64_t prof_t = __builtin_readcyclecounter(), prof_acc[10] = {}, prof_cnt[4] = {}
+__device__ unsigned long long g_par_prof[32];
+#define PROF_DECL      uint64_t prof_t = __builtin_readcyclecounter(), prof_acc[10] = {}, prof_cnt[4] = {}, prof_hist[12] = {}
 #define PROF_MARK(k)   { uint64_t t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; }
 #define PROF_COUNT(k, v) prof_cnt[k] += (v)
+#define PROF_HIST(v)   { _Pragma("unroll") for (int k_ = 0; k_ < 12; k_++) prof_hist[k_] += ((v) == k_ || (k_ == 11 && (v) > 11)); }
 #define PROF_FLUSH     if (lane == 0) { for (int k_ = 0; k_ < 10; k_++) atomicAdd(&g_par_prof[k_], prof_acc[k_]); \
-                                        for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_par_prof[10 + k_], prof_cnt[k_]); }
+                                        for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_par_prof[10 + k_], prof_cnt[k_]); \
+                                        for (int k_ = 0; k_ < 12; k_++) atomicAdd(&g_par_prof[16 + k_], prof_hist[k_]); }
 #else
 #define PROF_DECL
 #define PROF_MARK(k)
 #define PROF_COUNT(k, v)
+#define PROF_HIST(v)
 #define PROF_FLUSH
 #endif
 
@@ -1084,15 +1087,29 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     }
     PROF_MARK(1);
     bool counted = false;
-    for (int iter = 0; iter < 65; iter++) {
+    int  iter;
+    for (iter = 0; iter < 65; iter++) {
       uint32_t pe       = wave_read(sc.exit, lane ? lane - 1 : 0);
       uint64_t stopmask = __ballot(sc.stop != 0);
-      bool     dead     = (stopmask & ((1ull << lane) - 1ull)) != 0;   // behind the end of the block
-      bool     changed  = !dead && ((lane > 0 && pe != start) || !counted);   // every lane: one full scan at least
-      if (!__ballot(changed)) break;
-      if (iter > PAR_MAX_FIXUP) return false;        // codes that do not re-synchronise: serial passes
+      bool     dead     = (stopmask & ((1ull << lane) - 1ull)) != 0;   // behind a lane that stopped
+      // every lane does one full scan at least, then rescans whenever its predecessor leaves at
+      // another position than it started from (inside its own column: a predecessor that
+      // stopped early has nothing to tell).  Lanes behind a stop keep scanning, the stop may be
+      // an artefact of a chain that started wrong; they just do not keep the loop alive.
+      const bool moved  = lane > 0 && pe != start && pe >= limit - PAR_S;
+      bool     changed  = moved || !counted;
+      const uint64_t chg = __ballot(changed && !dead);
+      if (!chg) break;
+      // codes that do not re-synchronise (near fixed-length codes): most of the lanes in front
+      // of the first stop still start wrong after a full scan or two (typically under a fifth
+      // do), or the round needs many scans: serial passes
+      if (iter == 1 || iter == 2) {
+        const uint32_t live = stopmask ? (uint32_t)__builtin_ctzll(stopmask) + 1u : 64u;
+        if (live >= 8u && 2u * (uint32_t)__popcll(chg) > live) return false;
+      }
+      if (iter > PAR_MAX_FIXUP) return false;
       PROF_COUNT(1, 1);
-      start   = changed && lane > 0 ? pe : start;
+      start   = moved ? pe : start;
       counted = counted || changed;
       par_scan<true>(c, changed, B, start, limit, quarter, sc);
     }
@@ -1529,10 +1546,10 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
 
 #ifdef DEFL_PAR_PROFILE
 // Diagnostic builds only: read (and clear) the phase counters of huffman_block_parallel.
-extern "C" __attribute__((visibility("default"))) int infl_debug_par_profile(unsigned long long *out16) {
-  unsigned long long zero[16] = {};
+extern "C" __attribute__((visibility("default"))) int infl_debug_par_profile(unsigned long long *out32) {
+  unsigned long long zero[32] = {};
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(defl::g_par_prof), sizeof(zero)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(defl::g_par_prof), sizeof(zero)) != hipSuccess) return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(defl::g_par_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=8192)
     ap.add_argument("--pool", type=int, default=256)
+    ap.add_argument("--workload", default="text", choices=["text", "noise", "fixed"])
     args = ap.parse_args()
     from defl_amd import capi
     eng = capi.load()
@@ -33,11 +34,18 @@ def main():
     fn = eng.lib.infl_debug_par_profile
     fn.argtypes = [C.POINTER(C.c_ulonglong)]
     eng.lib.infl_gpu_set_table_variant(2)
-    comps = bench.build_pool(0, args.pool, 4)
+    if args.workload == "text":
+        comps = bench.build_pool(0, args.pool, 4)
+    elif args.workload == "fixed":
+        import zlib
+        comps = [wl.deflate(wl.text_stream(i), 6, True, zlib.Z_FIXED) for i in range(args.pool)]
+    else:
+        rng = np.random.default_rng(8)
+        comps = [wl.deflate(bytes(rng.integers(32, 96, 65536, dtype=np.uint8))) for i in range(args.pool)]
     comps = (comps * ((args.streams + args.pool - 1) // args.pool))[: args.streams]
     src, src_off, dst_off = wl.pack(comps, [bench.STREAM_BYTES] * len(comps))
     b = eng.device_batch(src, src_off, dst_off)
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 32)()
     b.run(1, detail=False)
     assert fn(buf) == 0                      # warm-up, cleared
     b.run(1, detail=False)
@@ -45,6 +53,7 @@ def main():
     v = np.array(list(buf), dtype=np.float64)
     _, status, outlen, _ = b.results(want_dst=False)
     assert (status == 0).all()
+    # (streams handed to the serial passes do not flush their counters: the shares describe the others)
     tot = v[:10].sum()
     n = len(comps)
     print("streams %d; wave cycles per stream %.0f" % (n, tot / n))
@@ -53,6 +62,8 @@ def main():
     rounds = v[10]
     print("rounds/stream %.2f; rescans/round %.2f; sweeps/round %.2f; lanes/round %.1f"
           % (rounds / n, v[11] / rounds, v[12] / rounds, v[13] / rounds))
+    print("full scans per round (share of rounds): " +
+          "  ".join("%d:%.2f%%" % (k, 100 * v[16 + k] / rounds) for k in range(12)))
 
 
 if __name__ == "__main__":
