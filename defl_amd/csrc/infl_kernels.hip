@@ -938,10 +938,12 @@ __device__ __forceinline__ void pl_init(ParLane &b, uint32_t p, uint32_t o, uint
   b.lim   = enable ? limit : 0u;
 }
 
-// Decodes the code at the lane's position.  `value`: literal byte, match length or distance - 1.
-// Returns the entry kind: 1 = literal, 2 = end of block, 3 = length, 4 = distance, 0 = malformed.
-// COUNT = false leaves out the byte count (the first scan only looks for where a chain ends).
-template <bool COUNT>
+// Decodes the code at the lane's position.  MODE 0: positions only (the first scan looks for
+// where a chain ends); MODE 1: also counts the bytes produced; MODE 2: also returns the entry
+// kind (1 = literal, 3 = length, 4 = distance, 0 = anything that ends the walk) and `value`:
+// literal byte, match length or distance - 1.  Whether a code runs past the end of the stream
+// is checked by the caller once per scan (the staged input is zero padded).
+template <int MODE>
 __device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_t &value) {
   typedef CompactFmt F;
   const uint32_t  b     = par_peek(c, r.p);
@@ -957,20 +959,24 @@ __device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_
   const bool     isbase = top == 1u;
   const uint32_t x      = isbase ? (e >> 4) & 15u : 0u;
   r.p += cl + x;
-  // literal/length table: top 2 -> literal, 1 -> length, 0 -> end of block unless e == 0
-  uint32_t kind = isd ? (isbase ? 4u : 0u) : (e == 0 ? 0u : islit ? 1u : isbase ? 3u : 2u);
-  if (COUNT) {
+  const bool nothing = isd ? !isbase : e == 0;       // no such code
+  const bool eob     = !isd && top == 0u && e != 0;
+  const bool goon    = isd ? isbase : top != 0u;     // neither of the two
+  const bool tomatch = !isd && isbase;
+  uint32_t   kind    = 0;
+  if (MODE >= 1) {
     const uint32_t extra = (b >> cl) & ((1u << x) - 1u);
     const uint32_t mant  = (((e >> 8) & 7u) << x) + extra;
     const uint32_t len   = (e & F::F_L258) ? 258u : 3u + mant;
-    value = isd ? mant : islit ? (e >> 4) & 0xffu : len;
     r.o += isd ? 0u : islit ? 1u : isbase ? len : 0u;
+    if (MODE == 2) {
+      value = isd ? mant : islit ? (e >> 4) & 0xffu : len;
+      kind  = !goon ? 0u : isd ? 4u : islit ? 1u : 3u;
+    }
   }
-  r.ph = (!isd && isbase) ? 1u : 0u;
-  if (r.p > c.total_bits) kind = 0;                  // would need bits past the end of the stream
-  const bool stop = kind == 0 || kind == 2;
-  r.st  = kind == 0 ? 2u : kind == 2 ? 1u : 0u;
-  r.lim = stop ? 0u : r.ph ? ~0u : r.limit;
+  r.ph  = tomatch ? 1u : 0u;
+  r.st  = nothing ? 2u : eob ? 1u : 0u;
+  r.lim = !goon ? 0u : tomatch ? ~0u : r.limit;
   return kind;
 }
 
@@ -1009,7 +1015,7 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
           sp = r.ph ? sp : r.p;
           so = r.ph ? so : r.o;
         }
-        pl_step<FULL>(r, c, value);
+        pl_step<FULL ? 1 : 0>(r, c, value);
       }
       it++;
     }
@@ -1022,6 +1028,7 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
       }
     }
   }
+  if (r.p > c.total_bits) r.st = 2;                  // a code that needs bits past the end of the stream
   if (enable) {
     const uint32_t fin = ((r.p - round0) << 12) | r.o;   // stretches never begun are empty
     s.ck[0] = nq > 0 ? ck[0] : fin;
@@ -1174,7 +1181,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
           if (rl.p < rl.lim) {
             uint32_t       value;
             const uint32_t at   = o0 + rl.o;
-            const uint32_t kind = pl_step<true>(rl, cq, value);
+            const uint32_t kind = pl_step<2>(rl, cq, value);
             if (kind == 1) P.link[at] = (uint16_t)(LK_LIT | value);
             if (kind == 3) oh = at;
             if (kind == 4) {
