@@ -925,8 +925,9 @@ __device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t p) {
 // whatever kind of code each of them meets.  A lane goes on while p < lim: lim is the end of
 // its stretch, everything while it is inside a match, nothing once it has stopped.
 struct ParLane {
-  uint32_t p, ph, o, st;         // bit position, phase, bytes produced, stop (0 none, 1 end of block, 2 malformed)
-  uint32_t lim, limit;
+  uint32_t p, ph, o;             // bit position, phase, bytes produced
+  uint32_t lim, limit, last;     // see above; the entry decoded last (0 = there was no such code)
+  uint32_t st;                   // 3 = stopped by the byte cap
 };
 
 __device__ __forceinline__ void pl_init(ParLane &b, uint32_t p, uint32_t o, uint32_t limit, bool enable) {
@@ -934,6 +935,7 @@ __device__ __forceinline__ void pl_init(ParLane &b, uint32_t p, uint32_t o, uint
   b.ph    = 0;
   b.o     = o;
   b.st    = 0;
+  b.last  = 1;
   b.limit = limit;
   b.lim   = enable ? limit : 0u;
 }
@@ -946,6 +948,7 @@ __device__ __forceinline__ void pl_init(ParLane &b, uint32_t p, uint32_t o, uint
 template <int MODE>
 __device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_t &value) {
   typedef CompactFmt F;
+  static_assert(F::F_LITERAL == 0x8000u && F::F_BASE == 0x4000u, "the entry classes are told apart by magnitude");
   const uint32_t  b     = par_peek(c, r.p);
   const bool      isd   = r.ph != 0;
   const uint32_t  mbits = isd ? (uint32_t)F::DIST_BITS : (uint32_t)F::LIT_BITS;
@@ -953,30 +956,33 @@ __device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_
   uint32_t        e     = tab[b & ((1u << mbits) - 1u)];
   if (e & F::F_SUB)                                  // second-level table (skipped when no lane needs it)
     e = tab[F::sub_at(e) + ((b >> mbits) & ((1u << (e & 15u)) - 1u))];
-  const uint32_t cl     = e & 15u;
-  const uint32_t top    = e >> 14;                   // 2 = literal, 1 = base + extra bits, 0 = end of block / nothing
-  const bool     islit  = top == 2u;
-  const bool     isbase = top == 1u;
-  const uint32_t x      = isbase ? (e >> 4) & 15u : 0u;
+  // Entry classes by magnitude: >= 0x8000 literal, >= 0x4000 base + extra bits (a length in the
+  // literal/length table, every entry of the distance table), below: end of block, 0 = no such
+  // code.  Each condition feeds selects directly; conditions are never combined.
+  const uint32_t cl      = e & 15u;
+  const bool     lit     = e >= 0x8000u;
+  const uint32_t x       = lit ? 0u : (e >> 4) & 15u;        // 0 by construction for the classes below
+  const bool     goon    = e >= 0x4000u;
+  const bool     tomatch = ((e >> 14) & 1u) > r.ph;          // a length code: the distance code follows
   r.p += cl + x;
-  const bool nothing = isd ? !isbase : e == 0;       // no such code
-  const bool eob     = !isd && top == 0u && e != 0;
-  const bool goon    = isd ? isbase : top != 0u;     // neither of the two
-  const bool tomatch = !isd && isbase;
-  uint32_t   kind    = 0;
+  uint32_t kind = 0;
   if (MODE >= 1) {
     const uint32_t extra = (b >> cl) & ((1u << x) - 1u);
     const uint32_t mant  = (((e >> 8) & 7u) << x) + extra;
     const uint32_t len   = (e & F::F_L258) ? 258u : 3u + mant;
-    r.o += isd ? 0u : islit ? 1u : isbase ? len : 0u;
+    r.o += tomatch ? len : e >> 15;                          // a distance entry adds nothing
     if (MODE == 2) {
-      value = isd ? mant : islit ? (e >> 4) & 0xffu : len;
-      kind  = !goon ? 0u : isd ? 4u : islit ? 1u : 3u;
+      value = lit ? (e >> 4) & 0xffu : len;
+      value = isd ? mant : value;
+      kind  = lit ? 1u : 3u;
+      kind  = isd ? 4u : kind;
+      kind  = goon ? kind : 0u;
     }
   }
-  r.ph  = tomatch ? 1u : 0u;
-  r.st  = nothing ? 2u : eob ? 1u : 0u;
-  r.lim = !goon ? 0u : tomatch ? ~0u : r.limit;
+  r.last = e;
+  r.ph   = tomatch ? 1u : 0u;
+  r.lim  = tomatch ? ~0u : r.limit;
+  r.lim  = goon ? r.lim : 0u;
   return kind;
 }
 
@@ -998,7 +1004,6 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
                                              ParScan &s) {
   ParLane  r;
   uint32_t it = 0, ck[3] = {0u, 0u, 0u};
-  uint32_t sp = start, so = 0;                       // where the symbol a lane is inside began
   int      nq = 0;
   bool     all_done = false;
   pl_init(r, start, 0, limit, enable);
@@ -1011,16 +1016,18 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
       }
       if (more) {
         uint32_t value;
-        if (FULL) {
-          sp = r.ph ? sp : r.p;
-          so = r.ph ? so : r.o;
-        }
         pl_step<FULL ? 1 : 0>(r, c, value);
       }
       it++;
     }
     if (FULL && q < 3 && !all_done) {
-      ck[q] = ((((r.ph ? sp : r.p)) - round0) << 12) | (r.ph ? so : r.o);
+      if (__ballot(r.ph != 0)) {                     // lanes inside a match finish it first
+        if (r.ph) {
+          uint32_t value;
+          pl_step<1>(r, c, value);
+        }
+      }
+      ck[q] = ((r.p - round0) << 12) | r.o;
       nq    = q + 1;
       if (!r.ph && r.o >= PAR_LANE_CAP && r.p < r.lim) {   // byte cap: the round ends with this lane
         r.st  = 3;
@@ -1028,7 +1035,10 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
       }
     }
   }
-  if (r.p > c.total_bits) r.st = 2;                  // a code that needs bits past the end of the stream
+  // why the lane stopped: byte cap (set above), no such code, end of block (the two ways a
+  // step ends a walk), or a code that needs bits past the end of the stream
+  if (!r.st && r.lim == 0) r.st = r.last == 0 ? 2u : 1u;
+  if (r.p > c.total_bits) r.st = 2;
   if (enable) {
     const uint32_t fin = ((r.p - round0) << 12) | r.o;   // stretches never begun are empty
     s.ck[0] = nq > 0 ? ck[0] : fin;
