@@ -1069,18 +1069,28 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     // stage the input of this round (coalesced, clamped inside the stream, zero padded)
     const uint32_t inbyte = (B >> 3) & ~3u;
     group_sync();
+#ifdef DEFL_PAR_PROFILE
+    __builtin_amdgcn_s_waitcnt(0);                   // everything outstanding (diagnostic split of the staging time)
+    PROF_MARK(9);
+#endif
+    {
+      constexpr int NW = (PAR_IN + 63) / 64;
+      uint32_t      raw[NW], sh[NW];
 #pragma unroll
-    for (int u = 0; u < (PAR_IN + 63) / 64; u++) {
-      uint32_t w   = (uint32_t)(u * 64 + lane);
-      uint32_t off = inbyte + 4u * w;
-      uint32_t q   = off < r.ilen4 ? off : r.ilen4;
-      uint32_t raw;
-      __builtin_memcpy(&raw, r.src + q, 4);
-      uint32_t d   = off - q;
-      uint32_t val = d >= 4 ? 0u : raw >> (8u * d);
-      uint32_t k = w & (uint32_t)(PAR_G - 1), col = w / (uint32_t)PAR_G;
-      if (col < 64u) P.in[k * 64u + col] = val;
-      if (k < 4u && col >= 1u && col <= 64u) P.in[(k + (uint32_t)PAR_G) * 64u + col - 1u] = val;
+      for (int u = 0; u < NW; u++) {                 // all loads first: one memory round trip
+        uint32_t off = inbyte + 4u * (uint32_t)(u * 64 + lane);
+        uint32_t q   = off < r.ilen4 ? off : r.ilen4;
+        __builtin_memcpy(&raw[u], r.src + q, 4);
+        sh[u] = off - q;
+      }
+#pragma unroll
+      for (int u = 0; u < NW; u++) {
+        uint32_t w   = (uint32_t)(u * 64 + lane);
+        uint32_t val = sh[u] >= 4 ? 0u : raw[u] >> (8u * sh[u]);
+        uint32_t k = w & (uint32_t)(PAR_G - 1), col = w / (uint32_t)PAR_G;
+        if (col < 64u) P.in[k * 64u + col] = val;
+        if (k < 4u && col >= 1u && col <= 64u) P.in[(k + (uint32_t)PAR_G) * 64u + col - 1u] = val;
+      }
     }
     group_sync();
     PROF_MARK(0);

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import workloads as wl  # noqa: E402
 
-PHASES = ["stage-in", "first scan", "fix-up", "place", "emit", "expand", "jump", "fetch+write"]
+PHASES = ["stage-in", "first scan", "fix-up", "place", "emit", "expand", "jump", "fetch+write", "?", "drain stores"]
 
 
 def main():
