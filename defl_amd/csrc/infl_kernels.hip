@@ -864,7 +864,7 @@ constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per round (
 constexpr int      PAR_IN       = 2 * PAR_S + 4;     // staged input words: 64 * PAR_S bits + 4 for the last column
 constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane stops scanning beyond this many bytes
 constexpr int      PAR_MAX_FIXUP = 8;                // full scans per round before the stream is handed to the serial passes
-constexpr int      PAR_U        = 8;                 // independent LDS/global accesses kept in flight
+constexpr int      PAR_U        = 4;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
 // Staged input words, one column per sub-sequence: row k of column l holds word l * PAR_G + k
@@ -881,7 +881,7 @@ static_assert((PAR_G & (PAR_G - 1)) == 0 && PAR_G >= 4, "sub-sequence length is 
 #endif
 struct alignas(16) ParLds {
   uint32_t in[PAR_ROWS * 64];
-  uint16_t link[PAR_R + 8 + DEFL_PAR_PAD / 2];       // 8: slack for whole-word reads at the end
+  uint16_t link[PAR_R + DEFL_PAR_PAD / 2];
 };
 
 // Optional cycle accounting of the phases (diagnostic builds only: make prof).
@@ -1174,7 +1174,8 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       //    per symbol at the symbol's first byte: a literal value, or a match as
       //    LK_EXT | (distance - 1).  Bytes inside a match stay 0.
       group_sync();
-      for (uint32_t i = (uint32_t)lane * 8u; i < total_out; i += 512) {
+      const uint32_t padded = (total_out + 255u) & ~255u;    // the per-byte passes work on whole 256-entry batches
+      for (uint32_t i = (uint32_t)lane * 8u; i < padded; i += 512) {
         uint4 z = {0u, 0u, 0u, 0u};
         __builtin_memcpy(&P.link[i], &z, 16);
       }
@@ -1229,11 +1230,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
           uint64_t heads[4];
           bool     own[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t i = base + 64u * u + (uint32_t)lane;
-            h[u] = P.link[i < total_out ? i : 0u];
-            h[u] = i < total_out ? h[u] : 0u;
-          }
+          for (int u = 0; u < 4; u++) h[u] = P.link[base + 64u * u + (uint32_t)lane];   // 0 behind the end
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             heads[u] = __ballot(h[u] != 0);
@@ -1251,7 +1248,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
               const uint32_t dd = (desc & 0x7fffu) + 1u;
               out = dd <= i ? i - dd : LK_EXT | (dd - i - 1u);
             }
-            if (i < total_out) P.link[i] = (uint16_t)out;
+            P.link[i] = (uint16_t)(i < total_out ? out : LK_LIT);   // padding: harmless literals
           }
         }
       }
@@ -1265,21 +1262,16 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       for (int it = 0; it < 16; it++) {
         PROF_COUNT(2, 1);
         bool more = false;
-        for (uint32_t base = (uint32_t)lane; base < total_out + (uint32_t)lane; base += 64 * PAR_U) {
+        for (uint32_t base = (uint32_t)lane; base < padded; base += 64 * PAR_U) {
           uint32_t v[PAR_U], t[PAR_U];
 #pragma unroll
-          for (int u = 0; u < PAR_U; u++) {
-            uint32_t i = base + 64u * u;
-            v[u] = P.link[i < total_out ? i : 0u];
-            v[u] = i < total_out ? v[u] : LK_LIT;
-          }
+          for (int u = 0; u < PAR_U; u++) v[u] = P.link[base + 64u * u];
 #pragma unroll
           for (int u = 0; u < PAR_U; u++) t[u] = P.link[(v[u] & (LK_LIT | LK_EXT)) ? 0u : v[u]];
 #pragma unroll
           for (int u = 0; u < PAR_U; u++) {
-            uint32_t i = base + 64u * u;
             uint32_t nv = (v[u] & (LK_LIT | LK_EXT)) ? v[u] : t[u];
-            if (i < total_out) P.link[i] = (uint16_t)nv;
+            P.link[base + 64u * u] = (uint16_t)nv;
             more |= !(nv & (LK_LIT | LK_EXT));
           }
         }
@@ -1289,24 +1281,37 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       PROF_MARK(6);
 
       // 5c. write out, one byte per lane and access (neighbouring lanes, neighbouring bytes:
-      //     the stores and most of the loads of bytes from before the group coalesce)
-      for (uint32_t base = (uint32_t)lane; base < total_out + (uint32_t)lane; base += 64 * PAR_U) {
-        uint32_t v[PAR_U], g[PAR_U];
+      //     the stores and most of the loads of bytes from before the group coalesce).  All loads
+      //     first, the bytes parked four to a register, then all stores: loads and stores share
+      //     one in-order counter, so a load behind a store would wait for the store to complete.
+      {
+        constexpr int NB = PAR_R / 256;
+        uint32_t      pk[NB];
 #pragma unroll
-        for (int u = 0; u < PAR_U; u++) {
-          const uint32_t i = base + 64u * u;
-          v[u] = P.link[i < total_out ? i : 0u];
-          v[u] = i < total_out ? v[u] : LK_LIT;
+        for (int bt = 0; bt < NB; bt++) {
+          pk[bt] = 0;
+          if ((uint32_t)bt * 256u < total_out) {
+            uint32_t v[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = P.link[bt * 256 + 64 * u + lane];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const uint32_t back = (v[u] & LK_EXT) ? (v[u] & 0x7fffu) + 1u : (pos ? 1u : 0u);
+              g[u] = dst[pos - back];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) pk[bt] |= (((v[u] & LK_EXT) ? g[u] : v[u]) & 0xffu) << (8 * u);
+          }
         }
 #pragma unroll
-        for (int u = 0; u < PAR_U; u++) {
-          const uint32_t back = (v[u] & LK_EXT) ? (v[u] & 0x7fffu) + 1u : (pos ? 1u : 0u);
-          g[u] = dst[pos - back];
-        }
+        for (int bt = 0; bt < NB; bt++) {
+          if ((uint32_t)bt * 256u < total_out) {
 #pragma unroll
-        for (int u = 0; u < PAR_U; u++) {
-          const uint32_t i = base + 64u * u;
-          if (i < total_out) dst[pos + i] = (uint8_t)((v[u] & LK_EXT) ? g[u] : v[u]);
+            for (int u = 0; u < 4; u++) {
+              const uint32_t i = (uint32_t)(bt * 256 + 64 * u + lane);
+              if (i < total_out) dst[pos + i] = (uint8_t)(pk[bt] >> (8 * u));
+            }
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -66,7 +66,7 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="stored,fixed,mixed,png")
+    ap.add_argument("--which", default="stored,fixed,mixed,runs,noisy,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
@@ -113,6 +113,32 @@ def main():
         comps = [wl.deflate(x) for x in raws]
         r = run_device(eng, oracle, comps, [65536] * 64, 1, 5, int(1024 * args.scale))
         print(json.dumps({"config": "6-bit noise (ratio %.4f)" % (sum(map(len, comps)) / (64 * 65536.0)), **r}), flush=True)
+    if "host" in which:
+        # host arenas through infl_batch(): upload, three launches, download (PCIe inclusive)
+        n = int(16384 * args.scale)
+        base = [wl.deflate(wl.text_stream(i)) for i in range(256)]
+        comps = [base[i % 256] for i in range(n)]
+        src, src_off, dst_off = wl.pack(comps, [65536] * n)
+        dst = np.zeros(int(dst_off[-1]), dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        outlen = np.zeros(n, dtype=np.uint32)
+        so = np.ascontiguousarray(src_off, dtype=np.uint64)
+        do = np.ascontiguousarray(dst_off, dtype=np.uint64)
+        fn = eng.lib.infl_batch
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+        fn.restype = C.c_int
+        call = lambda: fn(src.ctypes.data, so.ctypes.data, dst.ctypes.data, do.ctypes.data, 1, n,
+                          status.ctypes.data, outlen.ctypes.data)
+        assert call() == 0                      # warm-up (workspace allocation)
+        t0 = time.perf_counter()
+        assert call() == 0
+        dt = time.perf_counter() - t0
+        assert (status == 0).all() and (outlen == 65536).all()
+        want, _, _ = oracle.infl_batch(src[: int(so[64])], so[:65], do[:65], 1, 8)
+        assert np.array_equal(dst[: int(do[64])], want[: int(do[64])])
+        print(json.dumps({"config": "host arenas through infl_batch (PCIe inclusive)", "streams": n,
+                          "out_bytes": int(do[-1]), "in_bytes": int(so[-1]), "call_ms": round(dt * 1e3, 2),
+                          "decompressed_MB_per_s": round(int(do[-1]) / dt / 1e6, 1)}), flush=True)
     if "png" in which:
         n = int(4096 * args.scale)
         raws = [wl.png_like(i % 256) for i in range(n)]
