@@ -830,28 +830,33 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
 // The serial loops above advance one symbol per stream per pass over the
 // instruction stream, so a stream never goes faster than one dependency chain
 // allows.  Here the 64 lanes decode 64 consecutive sub-sequences of PAR_S bits
-// of the SAME block at once:
-//   1. scan      every lane decodes from its (guessed) start to the end of its
-//                sub-sequence and notes where it left it, how many bytes it
-//                would produce and whether it met the end-of-block code;
-//   2. fix up    a lane whose predecessor left at another bit position than the
-//                lane started from rescans from there; repeated until nothing
-//                changes.  DEFLATE symbol chains re-synchronise after ~10
-//                symbols, so this takes two or three rounds;
-//   3. place     a prefix sum of the byte counts gives every lane its output
-//                offset; as many lanes as fit the PAR_R-byte round buffer take
-//                part;
-//   4. emit      every lane walks its chain once more and writes one 16-bit
-//                "link" per output byte into LDS: a literal value, an index of
-//                an earlier byte of this round, or how far before the round the
-//                byte comes from (already final in global memory);
-//   5. resolve   bytes from before the round are fetched, then pointer jumping
-//                turns every link into a value (log2(chain depth) sweeps), and
-//                the round is written out with coalesced stores.
-// The next round starts where the last participating lane stopped.  Anything
-// unusual (malformed data on the true chain, output capacity, oversized lanes)
-// returns false and the stream is decoded again by the serial second pass, so
-// this function only has to be right when it succeeds.
+// of the SAME block at once.  Per round:
+//   1. stage     the round's input goes to LDS, one column per sub-sequence;
+//   2. scan      every lane decodes from its (guessed) start to the end of its
+//                sub-sequence and notes where it left it (positions only);
+//   3. fix up    every lane scans once more from where its predecessor left,
+//                now counting bytes and taking three checkpoints; a lane whose
+//                predecessor then leaves at yet another position rescans;
+//                repeated until nothing changes.  DEFLATE chains re-synchronise
+//                after ~128 bits on text, so a round takes 2.4 such scans.  Codes
+//                that do not re-synchronise (near fixed-length codes) are found
+//                out after one or two scans: the stream goes to the serial passes;
+//   4. place     a prefix sum of the byte counts gives every chain its output
+//                offset; the chains are then handled in groups of up to 16 whose
+//                bytes fit the PAR_R-entry link buffer;
+//   5. emit      four lanes share a chain (one stretch between checkpoints each)
+//                and write one 16-bit "head" per symbol at the symbol's first
+//                byte: a literal, or a match as flag | distance - 1;
+//   6. expand    every byte finds the head at or before it and becomes a literal,
+//                the index of an earlier byte of the group, or "n bytes before
+//                the group" (already final in global memory);
+//   7. resolve   pointer jumping until every link ends at a literal or before
+//                the group, then the bytes are written out (coalesced), those
+//                from before the group fetched on the way.
+// The next round starts where the last lane of the true chain stopped.  Anything
+// unusual (malformed data on the true chain, output capacity, chains longer
+// than the link buffer) returns false and the stream is decoded again by the
+// serial passes, so this function only has to be right when it succeeds.
 // ---------------------------------------------------------------------------
 #ifndef DEFL_PAR_S
 #define DEFL_PAR_S 256
@@ -860,9 +865,9 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
 #define DEFL_PAR_R 2048
 #endif
 constexpr int      PAR_S        = DEFL_PAR_S;        // sub-sequence length in bits
-constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per round (LDS links)
+constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per group of chains (LDS links)
 constexpr int      PAR_IN       = 2 * PAR_S + 4;     // staged input words: 64 * PAR_S bits + 4 for the last column
-constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane stops scanning beyond this many bytes
+constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane over this many bytes at a checkpoint ends the round
 constexpr int      PAR_MAX_FIXUP = 8;                // full scans per round before the stream is handed to the serial passes
 constexpr int      PAR_U        = 4;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
