@@ -1264,11 +1264,15 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       //     (both are position independent, so they can be copied along the chains).  Straight-
       //     line bodies (every access is made, harmless ones where nothing is to do) so that
       //     PAR_U independent accesses are in flight at once.
-      for (int it = 0; it < 16; it++) {
+      uint32_t dirty = ~0u;                          // batches that may still hold unresolved links
+      for (int it = 0; it < 16 && dirty; it++) {
         PROF_COUNT(2, 1);
-        bool more = false;
-        for (uint32_t base = (uint32_t)lane; base < padded; base += 64 * PAR_U) {
+        uint32_t again = 0;
+        for (uint32_t bt = 0; bt * 256u < padded; bt++) {
+          if (!((dirty >> bt) & 1u)) continue;       // wave-uniform
+          const uint32_t base = bt * 256u + (uint32_t)lane;
           uint32_t v[PAR_U], t[PAR_U];
+          bool     more = false;
 #pragma unroll
           for (int u = 0; u < PAR_U; u++) v[u] = P.link[base + 64u * u];
 #pragma unroll
@@ -1279,9 +1283,10 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
             P.link[base + 64u * u] = (uint16_t)nv;
             more |= !(nv & (LK_LIT | LK_EXT));
           }
+          if (__ballot(more)) again |= 1u << bt;
         }
         group_sync();
-        if (!__ballot(more)) break;
+        dirty = again;
       }
       PROF_MARK(6);
 
