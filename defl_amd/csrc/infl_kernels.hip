@@ -914,6 +914,11 @@ struct ParCtx {
   const uint16_t *lit, *dist;
 };
 
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {          // v is the same in every lane
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
 __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
 }
@@ -959,6 +964,12 @@ __device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_
   const uint32_t  mbits = isd ? (uint32_t)F::DIST_BITS : (uint32_t)F::LIT_BITS;
   const uint16_t *tab   = isd ? c.dist : c.lit;
   uint32_t        e     = tab[b & ((1u << mbits) - 1u)];
+#ifdef DEFL_PAR_PROFILE
+  if (threadIdx.x == (unsigned)__builtin_ctzll(__ballot(true))) {
+    atomicAdd(&g_par_prof[30], 1ull);
+    if (__ballot((e & F::F_SUB) != 0)) atomicAdd(&g_par_prof[31], 1ull);
+  }
+#endif
   if (e & F::F_SUB)                                  // second-level table (skipped when no lane needs it)
     e = tab[F::sub_at(e) + ((b >> mbits) & ((1u << (e & 15u)) - 1u))];
   // Entry classes by magnitude: >= 0x8000 literal, >= 0x4000 base + extra bits (a length in the
@@ -1515,8 +1526,14 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
   if (i >= n) return;
   if ((MODE == 2 || MODE == 4) && status[i] != INFL_STATUS_DEFERRED) return;
 
-  const uint64_t s0 = src_off[i], s1 = src_off[i + 1];
-  const uint64_t d0 = dst_off[i], d1 = dst_off[i + 1];
+  uint64_t s0 = src_off[i], s1 = src_off[i + 1];
+  uint64_t d0 = dst_off[i], d1 = dst_off[i + 1];
+  if constexpr (T == 64) {                           // one stream per wavefront: keep its bounds in scalar
+    s0 = wave_uniform(s0);                           // registers, so that addresses are base + 32-bit offset
+    s1 = wave_uniform(s1);
+    d0 = wave_uniform(d0);
+    d1 = wave_uniform(d1);
+  }
   uint32_t       out = 0, pos = 0;
   const uint8_t *cur = nullptr;
   int rc;

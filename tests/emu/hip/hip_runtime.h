@@ -51,6 +51,7 @@ void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
 }
+#define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_readlane(v, l) emu::bpermute((int)((l) << 2), (int)(v))
 
 static inline uint32_t __brev(uint32_t v) {
