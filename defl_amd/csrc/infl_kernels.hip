@@ -923,9 +923,9 @@ __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
 }
 
-// 32 bits of the stream from bit position p on (p inside the column, see ParLds)
-__device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t p) {
-  const uint32_t rel = p - c.colbit, k = (rel >> 5) * 64u;
+// 32 bits of the stream from bit `rel` of the column on (see ParLds)
+__device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t rel) {
+  const uint32_t k = (rel >> 5) * 64u;
   return __builtin_amdgcn_alignbit(c.col[k + 64u], c.col[k], rel);
 }
 
@@ -935,20 +935,23 @@ __device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t p) {
 // whatever kind of code each of them meets.  A lane goes on while p < lim: lim is the end of
 // its stretch, everything while it is inside a match, nothing once it has stopped.
 struct ParLane {
-  uint32_t p, ph, o;             // bit position, phase, bytes produced
+  uint32_t p, ph, o;             // bit position (relative to the lane's column), phase, bytes produced
   uint32_t lim, limit, last;     // see above; the entry decoded last (0 = there was no such code)
   uint32_t st;                   // 3 = stopped by the byte cap
 };
 
-__device__ __forceinline__ void pl_init(ParLane &b, uint32_t p, uint32_t o, uint32_t limit, bool enable) {
-  b.p     = p;
+// p and limit are positions in the stream; the lane keeps them relative to its column
+__device__ __forceinline__ void pl_init(ParLane &b, const ParCtx &c, uint32_t p, uint32_t o, uint32_t limit,
+                                        bool enable) {
+  b.p     = p - c.colbit;
   b.ph    = 0;
   b.o     = o;
   b.st    = 0;
   b.last  = 1;
-  b.limit = limit;
-  b.lim   = enable ? limit : 0u;
+  b.limit = limit - c.colbit;
+  b.lim   = enable ? b.limit : 0u;
 }
+__device__ __forceinline__ uint32_t pl_pos(const ParLane &b, const ParCtx &c) { return b.p + c.colbit; }
 
 // Decodes the code at the lane's position.  MODE 0: positions only (the first scan looks for
 // where a chain ends); MODE 1: also counts the bytes produced; MODE 2: also returns the entry
@@ -1022,7 +1025,7 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
   uint32_t it = 0, ck[3] = {0u, 0u, 0u};
   int      nq = 0;
   bool     all_done = false;
-  pl_init(r, start, 0, limit, enable);
+  pl_init(r, c, start, 0, limit, enable);
   for (int q = 0; q < 4 && !all_done; q++) {
     for (uint32_t k = 0; k < quarter || q == 3; k++) {
       const bool more = r.p < r.lim;
@@ -1043,7 +1046,7 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
           pl_step<1>(r, c, value);
         }
       }
-      ck[q] = ((r.p - round0) << 12) | r.o;
+      ck[q] = ((pl_pos(r, c) - round0) << 12) | r.o;
       nq    = q + 1;
       if (!r.ph && r.o >= PAR_LANE_CAP && r.p < r.lim) {   // byte cap: the round ends with this lane
         r.st  = 3;
@@ -1054,13 +1057,13 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
   // why the lane stopped: byte cap (set above), no such code, end of block (the two ways a
   // step ends a walk), or a code that needs bits past the end of the stream
   if (!r.st && r.lim == 0) r.st = r.last == 0 ? 2u : 1u;
-  if (r.p > c.total_bits) r.st = 2;
+  if (pl_pos(r, c) > c.total_bits) r.st = 2;
   if (enable) {
-    const uint32_t fin = ((r.p - round0) << 12) | r.o;   // stretches never begun are empty
+    const uint32_t fin = ((pl_pos(r, c) - round0) << 12) | r.o;   // stretches never begun are empty
     s.ck[0] = nq > 0 ? ck[0] : fin;
     s.ck[1] = nq > 1 ? ck[1] : fin;
     s.ck[2] = nq > 2 ? ck[2] : fin;
-    s.exit  = r.p;
+    s.exit  = pl_pos(r, c);
     s.nout  = r.o;
     s.stop  = r.st;
   }
@@ -1213,7 +1216,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
         cq.col    = P.in + chl;
         cq.colbit = inbyte * 8u + chl * PAR_S;
         group_sync();
-        pl_init(rl, act ? pb : B + chl * PAR_S, q ? kb & 0xfffu : 0u, pe, act);
+        pl_init(rl, cq, act ? pb : B + chl * PAR_S, q ? kb & 0xfffu : 0u, act ? pe : B + chl * PAR_S, act);
         while (__ballot(rl.p < rl.lim)) {
           if (rl.p < rl.lim) {
             uint32_t       value;
