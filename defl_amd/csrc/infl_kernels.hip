@@ -954,12 +954,13 @@ __device__ __forceinline__ void pl_init(ParLane &b, const ParCtx &c, uint32_t p,
 __device__ __forceinline__ uint32_t pl_pos(const ParLane &b, const ParCtx &c) { return b.p + c.colbit; }
 
 // Decodes the code at the lane's position.  MODE 0: positions only (the first scan looks for
-// where a chain ends); MODE 1: also counts the bytes produced; MODE 2: also returns the entry
-// kind (1 = literal, 3 = length, 4 = distance, 0 = anything that ends the walk) and `value`:
-// literal byte, match length or distance - 1.  Whether a code runs past the end of the stream
-// is checked by the caller once per scan (the staged input is zero padded).
+// where a chain ends); MODE 1: also counts the bytes produced; MODE 2: also returns `value`:
+// the literal byte, or distance - 1 after a distance code.  What kind of code it was shows in
+// the lane's state afterwards: ph = 1 after a length code, lim = 0 after anything that ends the
+// walk, lim = limit after a literal or a distance.  Whether a code runs past the end of the
+// stream is checked by the caller once per scan (the staged input is zero padded).
 template <int MODE>
-__device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_t &value) {
+__device__ __forceinline__ void pl_step(ParLane &r, const ParCtx &c, uint32_t &value) {
   typedef CompactFmt F;
   static_assert(F::F_LITERAL == 0x8000u && F::F_BASE == 0x4000u, "the entry classes are told apart by magnitude");
   const uint32_t  b     = par_peek(c, r.p);
@@ -984,25 +985,17 @@ __device__ __forceinline__ uint32_t pl_step(ParLane &r, const ParCtx &c, uint32_
   const bool     goon    = e >= 0x4000u;
   const bool     tomatch = ((e >> 14) & 1u) > r.ph;          // a length code: the distance code follows
   r.p += cl + x;
-  uint32_t kind = 0;
   if (MODE >= 1) {
     const uint32_t extra = (b >> cl) & ((1u << x) - 1u);
     const uint32_t mant  = (((e >> 8) & 7u) << x) + extra;
     const uint32_t len   = (e & F::F_L258) ? 258u : 3u + mant;
     r.o += tomatch ? len : e >> 15;                          // a distance entry adds nothing
-    if (MODE == 2) {
-      value = lit ? (e >> 4) & 0xffu : len;
-      value = isd ? mant : value;
-      kind  = lit ? 1u : 3u;
-      kind  = isd ? 4u : kind;
-      kind  = goon ? kind : 0u;
-    }
+    if (MODE == 2) value = isd ? mant : (e >> 4) & 0xffu;    // unused after a length code
   }
   r.last = e;
   r.ph   = tomatch ? 1u : 0u;
   r.lim  = tomatch ? ~0u : r.limit;
   r.lim  = goon ? r.lim : 0u;
-  return kind;
 }
 
 // Result of scanning one sub-sequence.  ck[k-1] (k = 1..3) packs the chain's state at the
@@ -1220,16 +1213,19 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
         while (__ballot(rl.p < rl.lim)) {
           if (rl.p < rl.lim) {
             uint32_t       value;
-            const uint32_t at   = o0 + rl.o;
-            const uint32_t kind = pl_step<2>(rl, cq, value);
-            if (kind == 1) P.link[at] = (uint16_t)(LK_LIT | value);
-            if (kind == 3) oh = at;
-            if (kind == 4) {
-              if (value >= pos + oh) {               // distance reaches before the output start
-                bad    = true;
-                rl.lim = 0;
-              }
-              P.link[oh] = (uint16_t)(LK_EXT | value);
+            const uint32_t at  = o0 + rl.o;
+            const bool     isd = rl.ph != 0;
+            pl_step<2>(rl, cq, value);
+            // one store serves both kinds of head: a literal at its own byte, a match (once its
+            // distance is known) at the byte the length code stood for; a length code stores nothing
+            const uint32_t where = isd ? oh : at;
+            const uint32_t head  = (isd ? LK_EXT : LK_LIT) | value;
+            const uint32_t dist  = isd ? value + 1u : 0u;
+            if (rl.lim == rl.limit) P.link[where] = (uint16_t)head;
+            oh = rl.ph ? at : oh;
+            if (dist > pos + where) {                // distance reaches before the output start
+              bad    = true;
+              rl.lim = 0;
             }
           }
         }
@@ -1263,9 +1259,9 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
             const uint32_t desc = own[u] ? d[u] : carry;
             if (heads[u]) carry = (uint32_t)__builtin_amdgcn_readlane((int)h[u], 63 - __builtin_clzll(heads[u]));
             uint32_t out = desc;
-            if (desc & LK_EXT) {
-              const uint32_t dd = (desc & 0x7fffu) + 1u;
-              out = dd <= i ? i - dd : LK_EXT | (dd - i - 1u);
+            if (desc >= LK_EXT) {                   // a match: distance dd = desc - LK_EXT + 1
+              const uint32_t dd = desc - (LK_EXT - 1u);
+              out = dd <= i ? i - dd : (LK_EXT - 1u) + dd - i;
             }
             P.link[i] = (uint16_t)(i < total_out ? out : LK_LIT);   // padding: harmless literals
           }
@@ -1289,13 +1285,12 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
           bool     more = false;
 #pragma unroll
           for (int u = 0; u < PAR_U; u++) v[u] = P.link[base + 64u * u];
-#pragma unroll
-          for (int u = 0; u < PAR_U; u++) t[u] = P.link[(v[u] & (LK_LIT | LK_EXT)) ? 0u : v[u]];
+#pragma unroll                                   // a resolved entry reads itself: no select afterwards
+          for (int u = 0; u < PAR_U; u++) t[u] = P.link[v[u] >= LK_LIT ? base + 64u * u : v[u]];
 #pragma unroll
           for (int u = 0; u < PAR_U; u++) {
-            uint32_t nv = (v[u] & (LK_LIT | LK_EXT)) ? v[u] : t[u];
-            P.link[base + 64u * u] = (uint16_t)nv;
-            more |= !(nv & (LK_LIT | LK_EXT));
+            P.link[base + 64u * u] = (uint16_t)t[u];
+            more |= t[u] < LK_LIT;
           }
           if (__ballot(more)) again |= 1u << bt;
         }
@@ -1320,11 +1315,11 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
             for (int u = 0; u < 4; u++) v[u] = P.link[bt * 256 + 64 * u + lane];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-              const uint32_t back = (v[u] & LK_EXT) ? (v[u] & 0x7fffu) + 1u : (pos ? 1u : 0u);
+              const uint32_t back = v[u] >= LK_EXT ? v[u] - (LK_EXT - 1u) : (pos ? 1u : 0u);
               g[u] = dst[pos - back];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) pk[bt] |= (((v[u] & LK_EXT) ? g[u] : v[u]) & 0xffu) << (8 * u);
+            for (int u = 0; u < 4; u++) pk[bt] |= ((v[u] >= LK_EXT ? g[u] : v[u]) & 0xffu) << (8 * u);
           }
         }
 #pragma unroll
