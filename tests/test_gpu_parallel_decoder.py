@@ -98,3 +98,42 @@ def test_bit_flips_in_long_streams(engine, oracle):
             m[i] ^= 1 << rng.randrange(8)
         streams.append(bytes(m))
     _check_batch(engine, oracle, streams, [80000] * len(streams), 1, 16, "flips", 2)
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_differential_fuzz_many_rounds(engine, oracle, seed):
+    """Mutated and truncated multi-round streams (several blocks, levels, strategies), random
+    capacities: status, length and bytes must match the oracle for every one of them."""
+    rng = random.Random(seed)
+    nrng = np.random.default_rng(seed)
+    bases = []
+    for k in range(12):
+        size = rng.randint(2000, 120000)
+        kind = k % 4
+        if kind == 0:
+            raw = _corpus(rng, size)
+        elif kind == 1:
+            raw = bytes(nrng.integers(97, 97 + rng.choice([2, 4, 16, 26]), size, dtype=np.uint8))
+        elif kind == 2:
+            raw = b"".join(bytes([rng.randrange(256)]) * rng.randint(1, 700) for _ in range(size // 300 + 1))[:size]
+        else:
+            raw = _corpus(rng, size // 2) + bytes(nrng.integers(0, 256, size - size // 2, dtype=np.uint8))
+        comp = _deflate_flushed(raw, rng, rng.choice([1, 6, 9])) if k % 3 == 0 else \
+            wl.deflate(raw, rng.choice([1, 6, 9]), True, rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE]))
+        bases.append((raw, comp))
+    streams, caps = [], []
+    for _ in range(600):
+        raw, comp = rng.choice(bases)
+        m = bytearray(comp)
+        what = rng.random()
+        if what < 0.45:
+            for _ in range(rng.randint(1, 4)):
+                m[rng.randrange(2, len(m))] ^= 1 << rng.randrange(8)
+        elif what < 0.7:
+            m = m[:rng.randrange(0, len(m))]
+        elif what < 0.8:
+            i = rng.randrange(2, len(m))
+            m[i:i + rng.randint(1, 40)] = bytes(rng.randrange(256) for _ in range(rng.randint(1, 40)))
+        streams.append(bytes(m))
+        caps.append(rng.choice([len(raw), len(raw), len(raw) + 100, max(0, len(raw) - rng.randint(1, 5000))]))
+    _check_batch(engine, oracle, streams, caps, 1, 16, "fuzz-%d" % seed, 2)
