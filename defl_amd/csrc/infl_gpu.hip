@@ -9,7 +9,10 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "../../include/defl/infl_batch.h"
 #include "infl_device.h"
@@ -196,11 +199,32 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
   }
   // Hand back exactly the bytes each stream produced; the rest of the caller's
   // destination is left untouched.
-  for (size_t i = 0; i < n; i++) {
-    size_t len = outlen[i], cap = (size_t)(dst_off[i + 1] - dst_off[i]);
-    if (len > cap) len = cap;
-    uint8_t *to = dst_ptrs ? (uint8_t *)dst_ptrs[i] : (uint8_t *)dst + dst_off[i];
-    if (len) memcpy(to, (const uint8_t *)w.hdst.p + dst_off[i], len);
+  auto scatter = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      size_t len = outlen[i], cap = (size_t)(dst_off[i + 1] - dst_off[i]);
+      if (len > cap) len = cap;
+      uint8_t *to = dst_ptrs ? (uint8_t *)dst_ptrs[i] : (uint8_t *)dst + dst_off[i];
+      if (len) memcpy(to, (const uint8_t *)w.hdst.p + dst_off[i], len);
+    }
+  };
+  // a few host threads for large batches: one core copies about 10 GB/s, the link twice that
+  const size_t nthreads = dst_bytes >= (32u << 20) && n >= 64 ? 8 : 1;
+  if (nthreads == 1) {
+    scatter(0, n);
+  } else {
+    std::vector<std::thread> pool;
+    size_t lo = 0;
+    for (size_t t = 1; t <= nthreads; t++) {         // equal byte shares, cut at stream boundaries
+      size_t hi = n;
+      if (t < nthreads) {
+        const uint64_t want = dst_off[n] / nthreads * t;
+        hi = (size_t)(std::lower_bound(dst_off, dst_off + n + 1, want) - dst_off);
+        hi = std::min(std::max(hi, lo), n);
+      }
+      if (hi > lo) pool.emplace_back(scatter, lo, hi);
+      lo = hi;
+    }
+    for (auto &th : pool) th.join();
   }
   return 0;
 }
