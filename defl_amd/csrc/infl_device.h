@@ -43,6 +43,13 @@ int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                       uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
                       int variant, void *stream);
 
+/* A pinned host buffer for gathering many streams' input before infl_rt_batch_host() (copies
+   from pinned memory run at the full link rate).  One buffer per process: returns NULL when it is
+   in use, when no device is usable or when pinning fails; the caller then uses ordinary memory.
+   Release after the batch call. */
+void *infl_rt_pinned_acquire(size_t bytes);
+void  infl_rt_pinned_release(void *p);
+
 /* Host-memory batch; used by infl(), infl_many() and infl_stream().  Stream i
    reads src[src_off[i] .. src_off[i+1]) and has dst_off[i+1] - dst_off[i] bytes
    of output capacity; its output goes to dst_ptrs[i] if dst_ptrs is given, else

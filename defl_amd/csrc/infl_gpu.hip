@@ -156,6 +156,23 @@ int infl_batch_dev_detail(const void *dev_src, const uint64_t *dev_src_off, void
                            dev_outlen, dev_detail, nullptr, g_lanes, g_variant, hip_stream);
 }
 
+static Buf  g_pin;                 // see infl_rt_pinned_acquire
+static bool g_pin_busy = false;
+static std::mutex g_pin_mu;
+
+void *infl_rt_pinned_acquire(size_t bytes) {
+  if (!device_ready()) return nullptr;
+  std::lock_guard<std::mutex> lock(g_pin_mu);
+  if (g_pin_busy || !host_reserve(g_pin, bytes + 16)) return nullptr;
+  g_pin_busy = true;
+  return g_pin.p;
+}
+
+void infl_rt_pinned_release(void *p) {
+  std::lock_guard<std::mutex> lock(g_pin_mu);
+  if (p && p == g_pin.p) g_pin_busy = false;
+}
+
 int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
                        const uint64_t *dst_off, void *const *dst_ptrs, int flags, size_t n,
                        int32_t *status, uint32_t *outlen, int32_t *detail, uint32_t *inpos) {

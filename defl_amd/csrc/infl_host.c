@@ -317,7 +317,7 @@ many_pass(infl_stream_t * const *streams, size_t n, int zlib, int32_t *status) {
   int32_t  *st_tmp;
   size_t   *idx;
   void    **dptr;
-  uint8_t  *src = NULL;
+  uint8_t  *src = NULL, *pinned = NULL;
   size_t    m = 0, stotal = 0, dtotal = 0;
   int       rc = 0;
 
@@ -353,7 +353,10 @@ many_pass(infl_stream_t * const *streams, size_t n, int zlib, int32_t *status) {
   soff[m] = stotal;
   doff[m] = dtotal;
 
-  src = (uint8_t *)calloc(1, stotal ? stotal : 1);
+  if (stotal >= (1u << 20))                       /* large gathers go to pinned memory if it is free */
+    src = pinned = (uint8_t *)infl_rt_pinned_acquire(stotal);
+  if (!src)
+    src = (uint8_t *)malloc(stotal ? stotal : 1);
   if (!src) {
     rc = UNZ_ENOMEM;
     goto out;
@@ -383,7 +386,10 @@ many_pass(infl_stream_t * const *streams, size_t n, int zlib, int32_t *status) {
   }
 out:
   free(soff); free(doff); free(outlen); free(inpos); free(st_tmp); free(idx); free(dptr);
-  free(src);
+  if (pinned)
+    infl_rt_pinned_release(pinned);
+  else
+    free(src);
   return rc;
 }
 
