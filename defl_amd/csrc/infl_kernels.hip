@@ -919,6 +919,24 @@ __device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {          // v is 
          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
+// inclusive maximum over the lanes at or below each lane (data-parallel-primitive row shifts and
+// row broadcasts: six vector instructions, no LDS)
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
+#define DEFL_DPP_MAX(ctrl, rows)                                                                   \
+  {                                                                                                 \
+    const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false);    \
+    v = v > t_ ? v : t_;                                                                            \
+  }
+  DEFL_DPP_MAX(0x111, 0xf)                           // row_shr:1, 2, 4, 8
+  DEFL_DPP_MAX(0x112, 0xf)
+  DEFL_DPP_MAX(0x114, 0xf)
+  DEFL_DPP_MAX(0x118, 0xf)
+  DEFL_DPP_MAX(0x142, 0xa)                           // row_bcast:15 into rows 1 and 3
+  DEFL_DPP_MAX(0x143, 0xc)                           // row_bcast:31 into rows 2 and 3
+#undef DEFL_DPP_MAX
+  return v;
+}
+
 __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
 }
@@ -1234,30 +1252,24 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       group_sync();
       PROF_MARK(4);
 
-      // 5a. expand: every byte finds the head at or before it (ballot + count-leading-zeros
-      //     inside a 64-byte chunk, the last head of earlier chunks carried along) and becomes a
-      //     literal, an index of an earlier byte of the group, or LK_EXT | how far before it.
+      // 5a. expand: every byte finds the head at or before it (a maximum scan over the 64 lanes
+      //     of a chunk, the last head of earlier chunks carried along) and becomes a literal, an
+      //     index of an earlier byte of the group, or LK_EXT | how far before it.
       {
-        const uint64_t le    = ~0ull >> (63 - lane); // lanes at or below this one
-        uint32_t       carry = 0;
+        uint32_t carry = 0;
         for (uint32_t base = 0; base < total_out; base += 256) {
-          uint32_t h[4], d[4];
-          uint64_t heads[4];
-          bool     own[4];
+          uint32_t h[4], s[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) h[u] = P.link[base + 64u * u + (uint32_t)lane];   // 0 behind the end
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            heads[u] = __ballot(h[u] != 0);
-            const uint64_t mine = heads[u] & le;
-            own[u] = mine != 0;
-            d[u]   = wave_read(h[u], own[u] ? 63u - (uint32_t)__builtin_clzll(mine) : (uint32_t)lane);
-          }
+#pragma unroll                                       // key = lane : head, so the maximum at or below a
+          for (int u = 0; u < 4; u++)                // lane is the nearest head, its value included
+            s[u] = wave_scan_max(h[u] ? ((uint32_t)lane << 16) | h[u] : 0u);
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t i    = base + 64u * u + (uint32_t)lane;
-            const uint32_t desc = own[u] ? d[u] : carry;
-            if (heads[u]) carry = (uint32_t)__builtin_amdgcn_readlane((int)h[u], 63 - __builtin_clzll(heads[u]));
+            const uint32_t desc = s[u] ? s[u] & 0xffffu : carry;
+            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)s[u], 63);
+            carry = last ? last & 0xffffu : carry;
             uint32_t out = desc;
             if (desc >= LK_EXT) {                   // a match: distance dd = desc - LK_EXT + 1
               const uint32_t dd = desc - (LK_EXT - 1u);

@@ -51,6 +51,22 @@ void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
 }
+// DPP controls used by the kernel: row_shr:n (0x110 + n) and the two row broadcasts; lanes whose
+// source lies outside their row of 16, or whose row is masked off, get `old`.
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int, bool) {
+  const int lane = emu::t_lane, row = lane >> 4;
+  int from = -1;
+  if (ctrl >= 0x111 && ctrl <= 0x11f) {
+    const int n = ctrl - 0x110;
+    if ((lane & 15) >= n) from = lane - n;
+  } else if (ctrl == 0x142) {                      // row_bcast:15
+    if (row >= 1) from = row * 16 - 1;
+  } else if (ctrl == 0x143) {                      // row_bcast:31
+    if (row >= 2) from = 31;
+  }
+  const int got = emu::bpermute((from < 0 ? lane : from) << 2, src);   // every lane takes part
+  return (from >= 0 && ((row_mask >> row) & 1)) ? got : old;
+}
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_readlane(v, l) emu::bpermute((int)((l) << 2), (int)(v))
 
