@@ -1256,26 +1256,28 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       //     of a chunk, the last head of earlier chunks carried along) and becomes a literal, an
       //     index of an earlier byte of the group, or LK_EXT | how far before it.
       {
+        // The key of a head is lane : head, so the maximum over the lanes at or below a byte is
+        // the nearest head with its value; lane 0 carries the last head of the chunks before in.
+        // Entries behind the end of the group (the batch's padding) become copies of the last
+        // symbol's links: valid, never written out.
         uint32_t carry = 0;
         for (uint32_t base = 0; base < total_out; base += 256) {
-          uint32_t h[4], s[4];
+          uint32_t h[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) h[u] = P.link[base + 64u * u + (uint32_t)lane];   // 0 behind the end
-#pragma unroll                                       // key = lane : head, so the maximum at or below a
-          for (int u = 0; u < 4; u++)                // lane is the nearest head, its value included
-            s[u] = wave_scan_max(h[u] ? ((uint32_t)lane << 16) | h[u] : 0u);
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t i    = base + 64u * u + (uint32_t)lane;
-            const uint32_t desc = s[u] ? s[u] & 0xffffu : carry;
-            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)s[u], 63);
-            carry = last ? last & 0xffffu : carry;
+            const uint32_t seed = lane == 0 ? carry : 0u;
+            const uint32_t s    = wave_scan_max(h[u] ? ((uint32_t)lane << 16) | h[u] : seed);
+            const uint32_t desc = s & 0xffffu;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)s, 63) & 0xffffu;
             uint32_t out = desc;
             if (desc >= LK_EXT) {                   // a match: distance dd = desc - LK_EXT + 1
               const uint32_t dd = desc - (LK_EXT - 1u);
               out = dd <= i ? i - dd : (LK_EXT - 1u) + dd - i;
             }
-            P.link[i] = (uint16_t)(i < total_out ? out : LK_LIT);   // padding: harmless literals
+            P.link[i] = (uint16_t)out;
           }
         }
       }
