@@ -998,10 +998,10 @@ __device__ __forceinline__ void pl_step(ParLane &r, const ParCtx &c, uint32_t &v
   // literal/length table, every entry of the distance table), below: end of block, 0 = no such
   // code.  Each condition feeds selects directly; conditions are never combined.
   const uint32_t cl      = e & 15u;
-  const bool     lit     = e >= 0x8000u;
-  const uint32_t x       = lit ? 0u : (e >> 4) & 15u;        // 0 by construction for the classes below
+  const uint32_t base    = (e >> 14) & 1u;                   // 1 for a base + extra bits entry only
+  const uint32_t x       = ((e >> 4) & 15u) * base;          // extra bits (a literal keeps its byte there)
   const bool     goon    = e >= 0x4000u;
-  const bool     tomatch = ((e >> 14) & 1u) > r.ph;          // a length code: the distance code follows
+  const bool     tomatch = base > r.ph;                      // a length code: the distance code follows
   r.p += cl + x;
   if (MODE >= 1) {
     const uint32_t extra = (b >> cl) & ((1u << x) - 1u);
