@@ -908,7 +908,8 @@ __device__ unsigned long long g_par_prof[32];
 #endif
 
 struct ParCtx {
-  const uint32_t *col;           // the lane's column of staged words (row stride 64)
+  const uint32_t *in;            // staged words (ParLds::in)
+  uint32_t        column;        // the lane's column there (row stride 64)
   uint32_t        colbit;        // bit position of the column's first word
   uint32_t        total_bits;    // stream length in bits
   const uint16_t *lit, *dist;
@@ -943,8 +944,9 @@ __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
 
 // 32 bits of the stream from bit `rel` of the column on (see ParLds)
 __device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t rel) {
-  const uint32_t k = (rel >> 5) * 64u;
-  return __builtin_amdgcn_alignbit(c.col[k + 64u], c.col[k], rel);
+  static_assert(PAR_ROWS <= 16, "the row index is masked to four bits");
+  const uint32_t k = (((rel >> 5) & 15u) << 6) | c.column;   // row : column (bit field + shift-or)
+  return __builtin_amdgcn_alignbit(c.in[k + 64u], c.in[k], rel);
 }
 
 // Per-lane decoder state.  One step decodes ONE code: a literal/length code (ph = 0) or,
@@ -1125,7 +1127,8 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     group_sync();
     PROF_MARK(0);
     ParCtx c;
-    c.col        = P.in + lane;
+    c.in         = P.in;
+    c.column     = (uint32_t)lane & 63u;            // (spelling out the range lets the address be an OR)
     c.colbit     = inbyte * 8u + (uint32_t)lane * PAR_S;
     c.total_bits = total_bits;
     c.lit        = lit;
@@ -1224,7 +1227,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
         ParCtx   cq  = c;                            // the chain's column instead of the lane's own
         uint32_t oh  = 0;
         bool     act = ch < a + nch && pb < pe;
-        cq.col    = P.in + chl;
+        cq.column = chl;
         cq.colbit = inbyte * 8u + chl * PAR_S;
         group_sync();
         pl_init(rl, cq, act ? pb : B + chl * PAR_S, q ? kb & 0xfffu : 0u, act ? pe : B + chl * PAR_S, act);
