@@ -988,7 +988,7 @@ __device__ __forceinline__ void pl_step(ParLane &r, const ParCtx &c, uint32_t &v
   const uint32_t  mbits = isd ? (uint32_t)F::DIST_BITS : (uint32_t)F::LIT_BITS;
   const uint16_t *tab   = isd ? c.dist : c.lit;
   uint32_t        e     = tab[b & ((1u << mbits) - 1u)];
-#ifdef DEFL_PAR_PROFILE
+#ifdef DEFL_PAR_PROFILE_STEPS                       // (atomics per step: distorts the cycle counts)
   if (threadIdx.x == (unsigned)__builtin_ctzll(__ballot(true))) {
     atomicAdd(&g_par_prof[30], 1ull);
     if (__ballot((e & F::F_SUB) != 0)) atomicAdd(&g_par_prof[31], 1ull);
@@ -1175,6 +1175,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     }
 
     PROF_MARK(2);
+    PROF_HIST(iter);
     // 3. place: lanes up to the first one that stopped inside its sub-sequence hold the true
     //    chain (the lanes behind it never learnt where to start: they wait for the next round)
     const uint64_t stopmask   = __ballot(sc.stop != 0);

@@ -62,7 +62,9 @@ def main():
     rounds = v[10]
     print("rounds/stream %.2f; rescans/round %.2f; sweeps/round %.2f; lanes/round %.1f"
           % (rounds / n, v[11] / rounds, v[12] / rounds, v[13] / rounds))
-    print("steps %d per stream, %.1f %% of them with a second-level lookup by some lane" % (v[30] / n, 100 * v[31] / max(1, v[30])))
+    if v[30]:
+        print("steps %d per stream, %.1f %% of them with a second-level lookup by some lane"
+              % (v[30] / n, 100 * v[31] / v[30]))
     print("full scans per round (share of rounds): " +
           "  ".join("%d:%.2f%%" % (k, 100 * v[16 + k] / rounds) for k in range(12)))
 
