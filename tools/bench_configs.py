@@ -66,7 +66,7 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="stored,fixed,mixed,runs,noisy,host,png")
+    ap.add_argument("--which", default="stored,fixed,mixed,runs,noisy,pngdev,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
@@ -113,6 +113,13 @@ def main():
         comps = [wl.deflate(x) for x in raws]
         r = run_device(eng, oracle, comps, [65536] * 64, 1, 5, int(1024 * args.scale))
         print(json.dumps({"config": "6-bit noise (ratio %.4f)" % (sum(map(len, comps)) / (64 * 65536.0)), **r}), flush=True)
+    if "pngdev" in which:
+        # the PNG-like scanline data of the IDAT configuration, device resident (kernel only)
+        raws = [wl.png_like(i) for i in range(256)]
+        comps = [wl.deflate(x) for x in raws]
+        r = run_device(eng, oracle, comps, [len(x) for x in raws], 1, 5, int(128 * args.scale))
+        print(json.dumps({"config": "PNG-like scanlines, device resident (ratio %.3f)"
+                                    % (sum(map(len, comps)) / float(sum(map(len, raws)))), **r}), flush=True)
     if "host" in which:
         # host arenas through infl_batch(): upload, three launches, download (PCIe inclusive)
         n = int(16384 * args.scale)
