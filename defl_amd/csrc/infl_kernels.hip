@@ -1327,27 +1327,32 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
 #pragma unroll
         for (int bt = 0; bt < NB; bt++) {
           pk[bt] = 0;
-          if ((uint32_t)bt * 256u < total_out) {
-            uint32_t v[4], g[4];
+          if ((uint32_t)bt * 256u < total_out) {     // four consecutive bytes per lane
+            uint64_t q;
+            __builtin_memcpy(&q, &P.link[bt * 256 + 4 * lane], 8);
+            uint32_t g[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = P.link[bt * 256 + 64 * u + lane];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const uint32_t back = v[u] >= LK_EXT ? v[u] - (LK_EXT - 1u) : (pos ? 1u : 0u);
-              g[u] = dst[pos - back];
+            for (int k = 0; k < 4; k++) {
+              const uint32_t v    = (uint32_t)(q >> (16 * k)) & 0xffffu;
+              const uint32_t back = v >= LK_EXT ? v - (LK_EXT - 1u) : (pos ? 1u : 0u);
+              g[k] = dst[pos - back];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) pk[bt] |= ((v[u] >= LK_EXT ? g[u] : v[u]) & 0xffu) << (8 * u);
+            for (int k = 0; k < 4; k++) {
+              const uint32_t v = (uint32_t)(q >> (16 * k)) & 0xffffu;
+              pk[bt] |= ((v >= LK_EXT ? g[k] : v) & 0xffu) << (8 * k);
+            }
           }
         }
 #pragma unroll
         for (int bt = 0; bt < NB; bt++) {
-          if ((uint32_t)bt * 256u < total_out) {
+          const uint32_t i = (uint32_t)(bt * 256 + 4 * lane);
+          if (i + 4u <= total_out) {
+            __builtin_memcpy(dst + pos + i, &pk[bt], 4);
+          } else {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const uint32_t i = (uint32_t)(bt * 256 + 64 * u + lane);
-              if (i < total_out) dst[pos + i] = (uint8_t)(pk[bt] >> (8 * u));
-            }
+            for (int k = 0; k < 3; k++)
+              if (i + (uint32_t)k < total_out) dst[pos + i + k] = (uint8_t)(pk[bt] >> (8 * k));
           }
         }
       }
