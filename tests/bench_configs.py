@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Secondary measurements on one GPU (not the headline): the parity-test configurations of the
+"""Test infrastructure (it checks every result against the CPU oracle, hence its place under tests/).
+Secondary measurements on one GPU (not the headline): the parity-test configurations of the
 build's measurement plan, each decoded from device-resident arenas and checked against the CPU
 oracle before a number is printed.
 
