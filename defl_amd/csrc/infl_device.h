@@ -37,11 +37,15 @@ extern "C" {
    lanes of a wavefront per stream (64/32/16/8).  variant 0 = one launch with
    tables in the reference's geometry; variant 1 = a first launch with compact
    16-bit tables (more streams in flight) plus a second launch in the
-   reference's geometry for the streams the first one deferred.  0 or -1. */
+   reference's geometry for the streams the first one deferred; variant 2 = a
+   wavefront-parallel launch first, then the two of variant 1 for what it
+   deferred.  `mirror` (may be NULL) is a second arena laid out like dst,
+   typically pinned host memory: every stream's output bytes are copied to the
+   same offsets there by the kernel that completes the stream.  0 or -1. */
 int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                       const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                       uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
-                      int variant, void *stream);
+                      int variant, void *mirror, void *stream);
 
 /* A pinned host buffer for gathering many streams' input before infl_rt_batch_host() (copies
    from pinned memory run at the full link rate).  One buffer per process: returns NULL when it is

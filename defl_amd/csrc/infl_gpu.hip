@@ -32,10 +32,37 @@ struct Buf {
 // One set per device the process has used.
 struct Workspace {
   Buf   src, dst, soff, doff, status, outlen, detail, inpos;   // device
-  Buf   hdst;                                            // pinned host staging
+  Buf   hdst, hmeta, hsrc;                               // pinned host staging: output bytes, the four result arrays, input
 };
 constexpr int MAX_DEV = 16;
 Workspace     g_ws[MAX_DEV];
+
+// Streams and events of the sliced host-memory path (default priority), made on first use.
+constexpr int      kPipeSlices     = 16;               // at most this many slices per call
+constexpr int      kPipeStreams    = 4;                // slices in flight
+constexpr size_t   kPipeMinBytes   = 64u << 20;        // smaller batches are not sliced
+constexpr size_t   kPipeMinStreams = 256;              // a slice holds at least this many streams
+struct Pipe {
+  hipStream_t st[kPipeStreams] = {}, up = nullptr;        // decode + download, in turn; uploads
+  hipEvent_t  ev[kPipeSlices] = {}, evu[kPipeSlices] = {};  // slice downloaded; slice uploaded
+  int         state               = 0;                 // 0 not tried, 1 ready, -1 failed
+};
+Pipe g_pipe[MAX_DEV];
+
+bool pipe_ready(int dev) {                             // caller holds g_mu
+  Pipe &p = g_pipe[dev];
+  if (p.state) return p.state > 0;
+  p.state = -1;
+  for (auto &s : p.st)
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+  if (hipStreamCreateWithFlags(&p.up, hipStreamNonBlocking) != hipSuccess) return false;
+  for (auto &e : p.ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+  for (auto &e : p.evu)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+  p.state = 1;
+  return true;
+}
 
 bool dev_reserve(Buf &b, size_t bytes) {
   if (bytes <= b.cap) return true;
@@ -143,7 +170,7 @@ int infl_batch_dev(const void *dev_src, const uint64_t *dev_src_off, void *dev_d
   if (n == 0) return 0;
   if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen) return -1;
   return infl_launch_batch(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status,
-                           dev_outlen, nullptr, nullptr, g_lanes, g_variant, hip_stream);
+                           dev_outlen, nullptr, nullptr, g_lanes, g_variant, nullptr, hip_stream);
 }
 
 // Same with the per-stream detail codes (INFL_D_*); for tests and diagnosis.
@@ -153,7 +180,7 @@ int infl_batch_dev_detail(const void *dev_src, const uint64_t *dev_src_off, void
   if (n == 0) return 0;
   if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen) return -1;
   return infl_launch_batch(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status,
-                           dev_outlen, dev_detail, nullptr, g_lanes, g_variant, hip_stream);
+                           dev_outlen, dev_detail, nullptr, g_lanes, g_variant, nullptr, hip_stream);
 }
 
 static Buf  g_pin;                 // see infl_rt_pinned_acquire
@@ -190,30 +217,9 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
       !dev_reserve(w.soff, off_bytes) || !dev_reserve(w.doff, off_bytes) ||
       !dev_reserve(w.status, n * 4) || !dev_reserve(w.outlen, n * 4) ||
       !dev_reserve(w.detail, n * 4) || !dev_reserve(w.inpos, n * 4) ||
-      !host_reserve(w.hdst, dst_bytes + 16))
+      !host_reserve(w.hdst, dst_bytes + 16) || !host_reserve(w.hmeta, 4 * n * 4))
     return -12;
 
-  hipStream_t st = nullptr;
-  bool ok = true;
-  if (src_bytes) ok &= hipMemcpyAsync(w.src.p, src, src_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok &= hipMemcpyAsync(w.soff.p, src_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok &= hipMemcpyAsync(w.doff.p, dst_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
-  if (!ok) return -1;
-  if (infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p,
-                        flags, n, (int32_t *)w.status.p, (uint32_t *)w.outlen.p,
-                        (int32_t *)w.detail.p, (uint32_t *)w.inpos.p, g_lanes, g_variant, st) != 0)
-    return -1;
-  ok &= hipMemcpyAsync(status, w.status.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-  ok &= hipMemcpyAsync(outlen, w.outlen.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-  if (detail) ok &= hipMemcpyAsync(detail, w.detail.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-  if (inpos) ok &= hipMemcpyAsync(inpos, w.inpos.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-  if (dst_bytes)
-    ok &= hipMemcpyAsync(w.hdst.p, w.dst.p, dst_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
-  ok &= hipStreamSynchronize(st) == hipSuccess;
-  if (!ok) {
-    (void)hipGetLastError();
-    return -1;
-  }
   // Hand back exactly the bytes each stream produced; the rest of the caller's
   // destination is left untouched.
   auto scatter = [&](size_t lo, size_t hi) {
@@ -224,26 +230,138 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
       if (len) memcpy(to, (const uint8_t *)w.hdst.p + dst_off[i], len);
     }
   };
-  // a few host threads for large batches: one core copies about 10 GB/s, the link twice that
-  const size_t nthreads = dst_bytes >= (32u << 20) && n >= 64 ? 8 : 1;
-  if (nthreads == 1) {
-    scatter(0, n);
-  } else {
-    std::vector<std::thread> pool;
-    size_t lo = 0;
-    for (size_t t = 1; t <= nthreads; t++) {         // equal byte shares, cut at stream boundaries
-      size_t hi = n;
-      if (t < nthreads) {
-        const uint64_t want = dst_off[n] / nthreads * t;
-        hi = (size_t)(std::lower_bound(dst_off, dst_off + n + 1, want) - dst_off);
-        hi = std::min(std::max(hi, lo), n);
-      }
-      if (hi > lo) pool.emplace_back(scatter, lo, hi);
-      lo = hi;
+  // first stream index at or behind which `want` destination bytes of [lo, n) lie
+  auto cut_at = [&](uint64_t want, size_t lo) {
+    size_t hi = (size_t)(std::lower_bound(dst_off, dst_off + n + 1, want) - dst_off);
+    return std::min(std::max(hi, lo), n);
+  };
+  // one core copies about 10 GB/s, the link five times that: `threads` equal byte shares of
+  // [lo, hi), cut at stream boundaries
+  auto scatter_threads = [&](std::vector<std::thread> &pool, size_t lo, size_t hi, size_t threads) {
+    const uint64_t b0 = dst_off[lo], b1 = dst_off[hi];
+    for (size_t t = 1; t <= threads && lo < hi; t++) {
+      const size_t cut = t < threads ? std::min(cut_at(b0 + (b1 - b0) / threads * t, lo), hi) : hi;
+      if (cut > lo) pool.emplace_back(scatter, lo, cut);
+      lo = cut;
     }
-    for (auto &th : pool) th.join();
+  };
+
+  std::vector<std::thread> pool;
+  bool ok = true;
+  if (dst_bytes < kPipeMinBytes || n < 2 * kPipeMinStreams || !pipe_ready(dev)) {
+    // small batch: upload, then decode (the kernels write the output to pinned memory), on the default stream
+    hipStream_t st = nullptr;
+    if (src_bytes) ok &= hipMemcpyAsync(w.src.p, src, src_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok &= hipMemcpyAsync(w.soff.p, src_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok &= hipMemcpyAsync(w.doff.p, dst_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (!ok) return -1;
+    if (infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p,
+                          flags, n, (int32_t *)w.status.p, (uint32_t *)w.outlen.p,
+                          (int32_t *)w.detail.p, (uint32_t *)w.inpos.p, g_lanes, g_variant, w.hdst.p, st) != 0)
+      return -1;
+    ok &= hipMemcpyAsync(status, w.status.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok &= hipMemcpyAsync(outlen, w.outlen.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (detail) ok &= hipMemcpyAsync(detail, w.detail.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (inpos) ok &= hipMemcpyAsync(inpos, w.inpos.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok &= hipStreamSynchronize(st) == hipSuccess;    // (the kernels wrote the output bytes to w.hdst themselves)
+    if (!ok) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    if (dst_bytes >= (32u << 20) && n >= 64) {
+      scatter_threads(pool, 0, n, 8);
+      for (auto &th : pool) th.join();
+    } else {
+      scatter(0, n);
+    }
+    return 0;
   }
-  return 0;
+
+  // Large batch: slices of whole streams go through upload -> decode on a few streams in
+  // turn; the decode kernels write every finished stream's bytes to the pinned buffer
+  // themselves (the `mirror` of infl_launch_batch), so the link carries data both ways while
+  // the kernels run, and host threads hand a slice's bytes to the caller while the next
+  // slices are still on their way.  The caller's pageable input is copied into pinned memory
+  // by a few threads, slice by slice (the runtime's own staging of pageable memory moves
+  // about 7 GB/s, one seventh of the link); the result arrays come back through pinned
+  // memory as well, so that no call here holds this thread until a slice's kernels are done.
+  Pipe      &pp     = g_pipe[dev];
+  const bool staged = src != g_pin.p;                  // (the gather buffer of infl_rt_pinned_acquire is pinned already)
+  if (staged && !host_reserve(w.hsrc, src_bytes + 16)) return -12;
+  const uint8_t *from = staged ? (const uint8_t *)w.hsrc.p : (const uint8_t *)src;
+  uint32_t      *hm   = (uint32_t *)w.hmeta.p;
+  size_t         cuts[kPipeSlices + 1];
+  int            nsl = 0, done = 0;
+  cuts[0] = 0;
+  // hands the slices whose download has completed to scatter threads (all of them if `wait`)
+  auto collect = [&](bool wait, bool last_too) {
+    while (ok && done < nsl) {
+      const hipError_t e = wait ? hipEventSynchronize(pp.ev[done]) : hipEventQuery(pp.ev[done]);
+      if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return;
+      }
+      if (e != hipSuccess) {
+        ok = false;
+        return;
+      }
+      const size_t lo = cuts[done], hi = cuts[done + 1], cnt = (hi - lo) * 4;
+      memcpy(status + lo, hm + lo, cnt);
+      memcpy(outlen + lo, hm + n + lo, cnt);
+      if (detail) memcpy(detail + lo, hm + 2 * n + lo, cnt);
+      if (inpos) memcpy(inpos + lo, hm + 3 * n + lo, cnt);
+      scatter_threads(pool, lo, hi, last_too && hi == n ? 8 : 2);
+      done++;
+    }
+  };
+  ok &= hipMemcpyAsync(w.soff.p, src_off, off_bytes, hipMemcpyHostToDevice, pp.up) == hipSuccess;
+  ok &= hipMemcpyAsync(w.doff.p, dst_off, off_bytes, hipMemcpyHostToDevice, pp.up) == hipSuccess;
+  const uint64_t slice_bytes = std::max<uint64_t>(kPipeMinBytes * 3 / 4, dst_bytes / (kPipeSlices - 1));
+  while (ok && cuts[nsl] < n && nsl < kPipeSlices) {
+    const size_t lo = cuts[nsl];
+    size_t       hi = nsl + 1 == kPipeSlices ? n : cut_at(dst_off[lo] + slice_bytes, lo);
+    hi = std::min(std::max(hi, std::min(lo + kPipeMinStreams, n)), n);
+    hipStream_t    st = pp.st[nsl % kPipeStreams];
+    const uint64_t s0 = src_off[lo], s1 = src_off[hi], d0 = dst_off[lo], d1 = dst_off[hi];
+    if (s1 > s0) {
+      if (staged) {
+        constexpr int T   = 4;
+        const size_t  len = s1 - s0;
+        std::thread   helper[T - 1];
+        auto part = [&](int t) {
+          const size_t a = len / T * t, b = t + 1 == T ? len : len / T * (t + 1);
+          memcpy((uint8_t *)w.hsrc.p + s0 + a, (const uint8_t *)src + s0 + a, b - a);
+        };
+        const bool many = len >= (1u << 20);
+        for (int t = 1; t < T && many; t++) helper[t - 1] = std::thread(part, t);
+        if (many) part(0); else memcpy((uint8_t *)w.hsrc.p + s0, (const uint8_t *)src + s0, len);
+        for (int t = 1; t < T && many; t++) helper[t - 1].join();
+      }
+      ok &= hipMemcpyAsync((uint8_t *)w.src.p + s0, from + s0, s1 - s0, hipMemcpyHostToDevice, pp.up) == hipSuccess;
+    }
+    ok &= hipEventRecord(pp.evu[nsl], pp.up) == hipSuccess;
+    ok &= hipStreamWaitEvent(st, pp.evu[nsl], 0) == hipSuccess;
+    ok = ok && infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p + lo, w.dst.p, (const uint64_t *)w.doff.p + lo,
+                                 flags, hi - lo, (int32_t *)w.status.p + lo, (uint32_t *)w.outlen.p + lo,
+                                 (int32_t *)w.detail.p + lo, (uint32_t *)w.inpos.p + lo, g_lanes, g_variant,
+                                 w.hdst.p, st) == 0;
+    const size_t cnt = (hi - lo) * 4;
+    ok &= hipMemcpyAsync(hm + lo, (int32_t *)w.status.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok &= hipMemcpyAsync(hm + n + lo, (uint32_t *)w.outlen.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (detail) ok &= hipMemcpyAsync(hm + 2 * n + lo, (int32_t *)w.detail.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (inpos) ok &= hipMemcpyAsync(hm + 3 * n + lo, (uint32_t *)w.inpos.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok &= hipEventRecord(pp.ev[nsl], st) == hipSuccess;
+    cuts[++nsl] = hi;
+    collect(false, false);
+  }
+  collect(true, true);
+  if (!ok) {                                           // let everything queued drain before the buffers are reused
+    (void)hipStreamSynchronize(pp.up);
+    for (auto &q : pp.st) (void)hipStreamSynchronize(q);
+    (void)hipGetLastError();
+  }
+  for (auto &th : pool) th.join();
+  return ok && cuts[nsl] == n ? 0 : -1;
 }
 
 int infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
@@ -255,3 +373,4 @@ int infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64
 }
 
 }  // extern "C"
+

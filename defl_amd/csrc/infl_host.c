@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #include "../../include/defl/infl.h"
 #include "../../include/defl/infl_batch.h"
@@ -309,6 +310,30 @@ infl_stream(infl_stream_t * __restrict st, const void * __restrict src, uint32_t
   }
 }
 
+/* chunk-list gather of streams [k0, k1) of a pass into its source arena */
+typedef struct gather_job_t {
+  infl_stream_t * const *streams;
+  const size_t          *idx;
+  const uint64_t        *soff;
+  uint8_t               *src;
+  size_t                 k0, k1;
+} gather_job_t;
+
+static void *
+gather_run(void *arg) {
+  const gather_job_t *g = (const gather_job_t *)arg;
+  for (size_t k = g->k0; k < g->k1; k++) {
+    const infl_stream_t *st = g->streams[g->idx[k]];
+    size_t               at = g->soff[k];
+    for (size_t j = 0; j < st->npieces; j++) {
+      if (st->pieces[j].len)
+        memcpy(g->src + at, st->pieces[j].p, st->pieces[j].len);
+      at += st->pieces[j].len;
+    }
+  }
+  return NULL;
+}
+
 /* one launch over the streams of `streams` whose zlib-ness equals `zlib` */
 static int
 many_pass(infl_stream_t * const *streams, size_t n, int zlib, int32_t *status) {
@@ -361,13 +386,25 @@ many_pass(infl_stream_t * const *streams, size_t n, int zlib, int32_t *status) {
     rc = UNZ_ENOMEM;
     goto out;
   }
-  for (size_t k = 0; k < m; k++) {               /* chunk-list gather */
-    const infl_stream_t *st = streams[idx[k]];
-    size_t               at = soff[k];
-    for (size_t j = 0; j < st->npieces; j++) {
-      if (st->pieces[j].len)
-        memcpy(src + at, st->pieces[j].p, st->pieces[j].len);
-      at += st->pieces[j].len;
+  {                                               /* chunk-list gather, by a few threads when it is large */
+    enum { GT = 4 };
+    gather_job_t job[GT];
+    pthread_t    th[GT];
+    int          started[GT] = {0};
+    const int    nt = (stotal >= (8u << 20) && m >= 4 * GT) ? GT : 1;
+    for (int t = 0; t < nt; t++) {
+      job[t].streams = streams; job[t].idx = idx; job[t].soff = soff; job[t].src = src;
+      job[t].k0 = m * (size_t)t / (size_t)nt;
+      job[t].k1 = m * (size_t)(t + 1) / (size_t)nt;
+    }
+    for (int t = 1; t < nt; t++)
+      started[t] = pthread_create(&th[t], NULL, gather_run, &job[t]) == 0;
+    gather_run(&job[0]);
+    for (int t = 1; t < nt; t++) {
+      if (started[t])
+        pthread_join(th[t], NULL);
+      else
+        gather_run(&job[t]);                      /* no thread to be had: this one does the share */
     }
   }
 

@@ -1509,6 +1509,25 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
   return rc;
 }
 
+// Copies the bytes a stream produced to the same offset of a second arena (host memory mapped
+// into the device's address space: the copy then is the stream's way to the host, made by the
+// lanes that decoded it, 16 bytes per lane and store once the addresses are aligned).
+template <int T>
+__device__ __forceinline__ void mirror_out(uint8_t *to, const uint8_t *from, uint64_t arena_off, uint32_t n,
+                                           int lig) {
+  uint32_t head = (16u - (uint32_t)(arena_off & 15u)) & 15u;
+  if (head > n) head = n;
+  if ((uint32_t)lig < head) to[lig] = from[lig];
+  if (T < 16 && (uint32_t)lig + T < head) to[lig + T] = from[lig + T];
+  const uint32_t body = (n - head) & ~15u;
+  for (uint32_t k = head + 16u * (uint32_t)lig; k < head + body; k += 16u * T) {
+    uint4 v;
+    __builtin_memcpy(&v, from + k, 16);
+    __builtin_memcpy(to + k, &v, 16);
+  }
+  for (uint32_t k = head + body + (uint32_t)lig; k < n; k += T) to[k] = from[k];
+}
+
 // flags: bit 0 = zlib wrapper (INFL_ZLIB); INFL_F_PROGRESS = publish the position
 // reached in `outlen` even when the stream stopped early (incremental API).
 //
@@ -1527,7 +1546,8 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
                                                         int32_t *__restrict__ status,
                                                         uint32_t *__restrict__ outlen,
                                                         int32_t *__restrict__ detail,
-                                                        uint32_t *__restrict__ inpos) {
+                                                        uint32_t *__restrict__ inpos,
+                                                        uint8_t *__restrict__ mirror) {
   constexpr int  G    = 64 / T;                    // streams per wavefront
   constexpr int  SYM  = (MODE == 1 || MODE == 4) ? 1 : MODE == 3 ? 2 : 0;
   static_assert(MODE != 3 || T == 64, "the parallel block decoder uses the whole wavefront");
@@ -1545,7 +1565,11 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
   const uint64_t i      = (uint64_t)blockIdx.x * G + group;
 
   if (i >= n) return;
-  if ((MODE == 2 || MODE == 4) && status[i] != INFL_STATUS_DEFERRED) return;
+  if (MODE == 2 || MODE == 4) {
+    const bool mine = status[i] == INFL_STATUS_DEFERRED;
+    group_sync();                                    // every lane has looked before one of them writes the result
+    if (!mine) return;
+  }
 
   uint64_t s0 = src_off[i], s1 = src_off[i + 1];
   uint64_t d0 = dst_off[i], d1 = dst_off[i + 1];
@@ -1567,15 +1591,20 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
     rc = inflate_stream<T, F, Reader, 0>(src + s0, (uint32_t)(s1 - s0), dst + d0,
                                          (uint32_t)(d1 - d0), (flags & 0xff) == 1, lds[group],
                                          nullptr, lig, gshift, out, pos, cur);
+  if ((MODE == 1 || MODE == 3 || MODE == 4) && rc != INFL_D_OK) {
+    if (lig == 0) status[i] = INFL_STATUS_DEFERRED;
+    return;
+  }
+  const uint32_t produced = ((flags & INFL_F_PROGRESS) && rc != INFL_D_OK && rc != INFL_D_INVALID) ? pos : out;
   if (lig == 0) {
-    if ((MODE == 1 || MODE == 3 || MODE == 4) && rc != INFL_D_OK) {
-      status[i] = INFL_STATUS_DEFERRED;
-      return;
-    }
     status[i] = rc == INFL_D_OK ? 0 : -1;          // every failure is UNZ_ERR (infl.c:1074-1087)
-    outlen[i] = ((flags & INFL_F_PROGRESS) && rc != INFL_D_OK && rc != INFL_D_INVALID) ? pos : out;
+    outlen[i] = produced;
     if (detail) detail[i] = rc;
     if (inpos) inpos[i] = (uint32_t)(cur - (src + s0));
+  }
+  if (mirror) {
+    group_sync();                                    // the lanes read what other lanes of the group wrote
+    mirror_out<T>(mirror + d0, dst + d0, d0, produced, lig);
   }
 }
 
@@ -1590,15 +1619,16 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                                  uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
-                                 int variant, void *stream) {
+                                 int variant, void *mirror, void *stream) {
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   auto s = (const uint8_t *)src;
   auto d = (uint8_t *)dst;
+  auto m = (uint8_t *)mirror;
 #define LAUNCH(T, FMT, MODE)                                                                   \
   hipLaunchKernelGGL((defl::infl_batch_kernel<T, defl::FMT, MODE>),                            \
                      dim3((unsigned)((n + (64 / T) - 1) / (64 / T))), dim3(64), 0, st, s, src_off, \
-                     d, dst_off, flags, n, status, outlen, detail, inpos)
+                     d, dst_off, flags, n, status, outlen, detail, inpos, m)
 #define LAUNCH_T(T)             \
   if (variant == 0) {           \
     LAUNCH(T, RefFmt, 0);       \

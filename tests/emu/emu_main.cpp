@@ -66,11 +66,11 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
 
 extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
                               int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
-                              uint32_t *inpos, int lanes, int variant) {
+                              uint32_t *inpos, int lanes, int variant, void *mirror) {
   if (variant >= 2) lanes = 64;   // the parallel pass is a 64-lane kernel; one group size per run here
   emu::g_lanes_per_group = lanes;
   return infl_launch_batch(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, variant,
-                           nullptr);
+                           mirror, nullptr);
 }
 
 // emu_run <in.bin> <out.bin> <lanes> <flags> <variant>
@@ -80,6 +80,7 @@ extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *ds
 // past a stream's input or output capacity at the arena ends.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 int main(int argc, char **argv) {
   if (argc < 6) return 2;
@@ -95,9 +96,26 @@ int main(int argc, char **argv) {
   fclose(f);
   std::vector<int32_t>  status(n, -99), detail(n, -99);
   std::vector<uint32_t> outlen(n, 0), inpos(n, 0);
+  // a second arena takes the copy every stream's output gets on its way to the host
+  uint8_t *mirror = (uint8_t *)malloc(dof[n] ? dof[n] : 1);
+  memset(mirror, 0x5a, dof[n] ? dof[n] : 1);
   int rc = emu_infl_batch(src, so.data(), dst, dof.data(), atoi(argv[4]), n, status.data(), outlen.data(),
-                          detail.data(), inpos.data(), atoi(argv[3]), atoi(argv[5]));
+                          detail.data(), inpos.data(), atoi(argv[3]), atoi(argv[5]), mirror);
   if (rc != 0) return 3;
+  for (uint64_t i = 0; i < n; i++) {                 // exactly the produced bytes, nothing around them
+    const uint64_t a = dof[i], e = dof[i + 1];
+    uint64_t       m = outlen[i] < e - a ? outlen[i] : e - a;
+    if (memcmp(mirror + a, dst + a, m) != 0) {
+      fprintf(stderr, "mirror differs in stream %llu\n", (unsigned long long)i);
+      return 4;
+    }
+    for (uint64_t k = a + m; k < e; k++)
+      if (mirror[k] != 0x5a) {
+        fprintf(stderr, "mirror written behind the output of stream %llu\n", (unsigned long long)i);
+        return 4;
+      }
+  }
+  free(mirror);
   f = fopen(argv[2], "wb");
   fwrite(status.data(), 4, n, f);
   fwrite(outlen.data(), 4, n, f);

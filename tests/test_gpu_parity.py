@@ -230,6 +230,54 @@ def test_host_batch_and_many(engine, oracle):
         lib.infl_destroy(sts[i])
 
 
+def test_host_batch_sliced_large(engine, oracle):
+    """A host-memory batch large enough for the sliced path of infl_batch() (slices of whole
+    streams uploaded, decoded and downloaded in turn): ragged stream sizes and capacities,
+    damaged and truncated streams in between, and the bytes behind every stream's output left
+    as the caller had them."""
+    rng = random.Random(77)
+    base_raw = [wl.text_stream(i, rng.choice([700, 9000, 65536, 150000])) for i in range(48)]
+    base = [wl.deflate(r) for r in base_raw]
+    streams, caps = [], []
+    for i in range(3000):
+        k = rng.randrange(len(base))
+        s = base[k]
+        cap = len(base_raw[k]) + rng.choice([0, 0, 1, 300])
+        kind = rng.randrange(20)
+        if kind == 0:
+            s = s[: rng.randrange(len(s))]
+        elif kind == 1:
+            b = bytearray(s)
+            b[rng.randrange(2, len(b))] ^= 1 << rng.randrange(8)
+            s = bytes(b)
+        elif kind == 2:
+            cap = rng.randrange(len(base_raw[k]))
+        streams.append(s)
+        caps.append(cap)
+    src, src_off, dst_off = wl.pack(streams, caps)
+    assert int(dst_off[-1]) > (96 << 20)
+    want_dst, want_status, want_outlen = oracle.infl_batch(src, src_off, dst_off, 1, 8)
+    n = len(streams)
+    dst = np.full(int(dst_off[-1]) + 64, 0xA5, dtype=np.uint8)
+    status = np.full(n, -77, dtype=np.int32)
+    outlen = np.zeros(n, dtype=np.uint32)
+    so = np.ascontiguousarray(src_off, dtype=np.uint64)
+    do = np.ascontiguousarray(dst_off, dtype=np.uint64)
+    for rep in range(2):                                 # the second call reuses the workspace
+        rc = engine.lib.infl_batch(src.ctypes.data, so.ctypes.data, dst.ctypes.data, do.ctypes.data, 1, n,
+                                   status.ctypes.data, outlen.ctypes.data)
+        assert rc == 0
+        assert np.array_equal(status, want_status) and np.array_equal(outlen, want_outlen)
+        ok = want_status == 0
+        assert 0.8 < ok.mean() < 1.0
+        for i in range(n):
+            a, m, e = int(dst_off[i]), int(outlen[i]), int(dst_off[i + 1])
+            if ok[i]:
+                assert np.array_equal(dst[a:a + m], want_dst[a:a + m]), i
+                assert (dst[a + m:e] == 0xA5).all(), i
+        assert (dst[int(dst_off[-1]):] == 0xA5).all()
+
+
 def test_chunked_include_like_reference(engine):
     """test_file_chunked of the reference (test_files.c:260-331): 1/2/4/8-byte pieces."""
     for name in ("hello", "large_text_64k", "multiple_blocks", "png_simulation", "uncompressed_multi"):
