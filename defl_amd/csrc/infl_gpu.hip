@@ -160,7 +160,12 @@ int infl_gpu_set_lanes_per_stream(int lanes) {
 }
 
 int infl_gpu_set_table_variant(int variant) {
-  if (variant >= 0 && variant <= 2) g_variant = variant;
+#ifdef DEFL_PAR_PROFILE
+  constexpr int kMaxVariant = 3;   // diagnostic builds: the parallel pass alone, handed-over streams keep their mark
+#else
+  constexpr int kMaxVariant = 2;
+#endif
+  if (variant >= 0 && variant <= kMaxVariant) g_variant = variant;
   return g_variant;
 }
 

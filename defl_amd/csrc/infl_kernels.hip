@@ -838,9 +838,10 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
 //                now counting bytes and taking three checkpoints; a lane whose
 //                predecessor then leaves at yet another position rescans;
 //                repeated until nothing changes.  DEFLATE chains re-synchronise
-//                after ~128 bits on text, so a round takes 2.4 such scans.  Codes
-//                that do not re-synchronise (near fixed-length codes) are found
-//                out after one or two scans: the stream goes to the serial passes;
+//                after ~128 bits on text, so a round takes 2.4 such scans.  With
+//                codes that re-synchronise badly (near fixed-length codes) a round
+//                is cut short after PAR_MAX_FIXUP scans, in front of the first
+//                lane that still starts wrong;
 //   4. place     a prefix sum of the byte counts gives every chain its output
 //                offset; the chains are then handled in groups of up to 16 whose
 //                bytes fit the PAR_R-entry link buffer;
@@ -868,7 +869,10 @@ constexpr int      PAR_S        = DEFL_PAR_S;        // sub-sequence length in b
 constexpr int      PAR_R        = DEFL_PAR_R;        // output bytes per group of chains (LDS links)
 constexpr int      PAR_IN       = 2 * PAR_S + 4;     // staged input words: 64 * PAR_S bits + 4 for the last column
 constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane over this many bytes at a checkpoint ends the round
-constexpr int      PAR_MAX_FIXUP = 8;                // full scans per round before the stream is handed to the serial passes
+#ifndef DEFL_PAR_MAX_FIXUP
+#define DEFL_PAR_MAX_FIXUP 16
+#endif
+constexpr int      PAR_MAX_FIXUP = DEFL_PAR_MAX_FIXUP;   // counting scans per round before the round is cut short
 constexpr int      PAR_U        = 4;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
@@ -896,6 +900,7 @@ __device__ unsigned long long g_par_prof[32];
 #define PROF_MARK(k)   { uint64_t t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; }
 #define PROF_COUNT(k, v) prof_cnt[k] += (v)
 #define PROF_HIST(v)   { _Pragma("unroll") for (int k_ = 0; k_ < 12; k_++) prof_hist[k_] += ((v) == k_ || (k_ == 11 && (v) > 11)); }
+#define PROF_BAIL(k)   { if (lane == 0) atomicAdd(&g_par_prof[k], 1ull); }
 #define PROF_FLUSH     if (lane == 0) { for (int k_ = 0; k_ < 10; k_++) atomicAdd(&g_par_prof[k_], prof_acc[k_]); \
                                         for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_par_prof[10 + k_], prof_cnt[k_]); \
                                         for (int k_ = 0; k_ < 12; k_++) atomicAdd(&g_par_prof[16 + k_], prof_hist[k_]); }
@@ -904,6 +909,7 @@ __device__ unsigned long long g_par_prof[32];
 #define PROF_MARK(k)
 #define PROF_COUNT(k, v)
 #define PROF_HIST(v)
+#define PROF_BAIL(k)
 #define PROF_FLUSH
 #endif
 
@@ -1146,8 +1152,9 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       quarter = q4 < 4u ? 4u : q4;
     }
     PROF_MARK(1);
-    bool counted = false;
-    int  iter;
+    bool     counted = false;
+    uint32_t trunc   = 64u;                          // lanes in front of the first one that still starts wrong
+    int      iter;
     for (iter = 0; iter < 65; iter++) {
       uint32_t pe       = wave_read(sc.exit, lane ? lane - 1 : 0);
       uint64_t stopmask = __ballot(sc.stop != 0);
@@ -1160,14 +1167,16 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       bool     changed  = moved || !counted;
       const uint64_t chg = __ballot(changed && !dead);
       if (!chg) break;
-      // codes that do not re-synchronise (near fixed-length codes): most of the lanes in front
-      // of the first stop still start wrong after a full scan or two (typically under a fifth
-      // do), or the round needs many scans: serial passes
-      if (iter == 1 || iter == 2) {
-        const uint32_t live = stopmask ? (uint32_t)__builtin_ctzll(stopmask) + 1u : 64u;
-        if (live >= 8u && 2u * (uint32_t)__popcll(chg) > live) return false;
+      // a round that needs many scans ends in front of the first lane that still starts wrong
+      // (the lanes before it hold the true chain; lane 0 always does, and every scan adds one
+      // lane at least), the rest waits for the next round.  Codes that re-synchronise badly
+      // (near fixed-length codes) thus cost short rounds, never the stream: handing such a stream
+      // to the serial passes was measured slower on every workload tried, and one stream in a
+      // serial pass takes about as long as a whole batch in this one.
+      if (iter > PAR_MAX_FIXUP) {
+        trunc = (uint32_t)__builtin_ctzll(chg);
+        break;
       }
-      if (iter > PAR_MAX_FIXUP) return false;
       PROF_COUNT(1, 1);
       start   = moved ? pe : start;
       counted = counted || changed;
@@ -1180,10 +1189,17 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     //    chain (the lanes behind it never learnt where to start: they wait for the next round)
     const uint64_t stopmask   = __ballot(sc.stop != 0);
     const uint32_t first_stop = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : 64u;
-    const uint32_t why        = first_stop < 64 ? wave_read(sc.stop, first_stop) : 0u;
-    if (why == 2) return false;                      // malformed on the true chain
-    if (why == 3 && first_stop < 8) return false;    // very long matches: the serial copy loops do better
-    const uint32_t nact = first_stop < 64 ? first_stop + 1u : 64u;
+    const bool     cut        = trunc <= first_stop; // the round was cut short in front of any stop
+    const uint32_t why        = !cut && first_stop < 64 ? wave_read(sc.stop, first_stop) : 0u;
+    if (why == 2) {                                  // malformed on the true chain
+      PROF_BAIL(29);
+      return false;
+    }
+    if (why == 3 && first_stop < 8) {                // very long matches: the serial copy loops do better
+      PROF_BAIL(28);
+      return false;
+    }
+    const uint32_t nact = cut ? trunc : first_stop < 64 ? first_stop + 1u : 64u;
     uint32_t       cum  = (uint32_t)lane < nact ? sc.nout : 0;
     for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
       uint32_t t = wave_read(cum, (uint32_t)lane >= dlt ? lane - dlt : 0);

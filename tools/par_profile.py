@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=8192)
     ap.add_argument("--pool", type=int, default=256)
-    ap.add_argument("--workload", default="text", choices=["text", "noise", "fixed"])
+    ap.add_argument("--workload", default="text", choices=["text", "noise", "fixed", "png", "mixed"])
     args = ap.parse_args()
     from defl_amd import capi
     eng = capi.load()
@@ -39,11 +39,22 @@ def main():
     elif args.workload == "fixed":
         import zlib
         comps = [wl.deflate(wl.text_stream(i), 6, True, zlib.Z_FIXED) for i in range(args.pool)]
+    elif args.workload == "png":
+        caps = [len(wl.png_like(i)) for i in range(args.pool)]
+        comps = [wl.deflate(wl.png_like(i)) for i in range(args.pool)]
+    elif args.workload == "mixed":
+        rng = np.random.default_rng(5)
+        caps = [int(x) for x in np.exp(rng.uniform(np.log(1024), np.log(262144), args.pool))]
+        comps = [wl.deflate(wl.text_stream(1000 + i, sz)) for i, sz in enumerate(caps)]
     else:
         rng = np.random.default_rng(8)
         comps = [wl.deflate(bytes(rng.integers(32, 96, 65536, dtype=np.uint8))) for i in range(args.pool)]
-    comps = (comps * ((args.streams + args.pool - 1) // args.pool))[: args.streams]
-    src, src_off, dst_off = wl.pack(comps, [bench.STREAM_BYTES] * len(comps))
+    if args.workload not in ("png", "mixed"):
+        caps = [bench.STREAM_BYTES] * len(comps)
+    reps = (args.streams + args.pool - 1) // args.pool
+    comps = (comps * reps)[: args.streams]
+    caps = (caps * reps)[: args.streams]
+    src, src_off, dst_off = wl.pack(comps, caps)
     b = eng.device_batch(src, src_off, dst_off)
     buf = (C.c_ulonglong * 32)()
     b.run(1, detail=False)
@@ -53,6 +64,15 @@ def main():
     v = np.array(list(buf), dtype=np.float64)
     _, status, outlen, _ = b.results(want_dst=False)
     assert (status == 0).all()
+    # how many streams the parallel pass hands over to the serial passes (diagnostic variant 3:
+    # the parallel pass alone, handed-over streams keep their mark)
+    if eng.lib.infl_gpu_set_table_variant(3) == 3:
+        b.run(1, detail=False)
+        assert fn(buf) == 0
+        _, st3, _, _ = b.results(want_dst=False)
+        print("handed over to the serial passes: %d of %d streams" % (int((st3 != 0).sum()), len(st3)))
+        print("  blocks handed over because: very long matches %d, malformed %d" % (buf[28], buf[29]))
+        eng.lib.infl_gpu_set_table_variant(2)
     # (streams handed to the serial passes do not flush their counters: the shares describe the others)
     tot = v[:10].sum()
     n = len(comps)
