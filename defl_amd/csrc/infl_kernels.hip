@@ -755,20 +755,30 @@ __device__ __forceinline__ int huffman_block(R &r, uint8_t *dst, uint32_t &pos_i
 // caller checks once, when the stream is finished, that no bit past the end was
 // consumed (a stream that needs such bits is rejected by the reference, so it
 // goes to the second pass).  Output bounds are checked per symbol.
-template <int T>
-__device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t *dst, uint32_t &pos_io,
-                                                      uint32_t cap, const uint16_t *lit,
-                                                      const uint16_t *dist, int lig) {
+//
+// BOUNDED: the loop also ends, at a symbol boundary, once the input position has reached
+// `stop_bits` (the parallel block decoder has stretches of very long matches decoded here).
+// Returns COMPACT_END (the end-of-block code has been consumed), COMPACT_STOP (BOUNDED only) or
+// COMPACT_FAIL.
+enum : int { COMPACT_FAIL = 0, COMPACT_END = 1, COMPACT_STOP = 2 };
+template <int T, bool BOUNDED = false>
+__device__ __forceinline__ int huffman_block_compact(FastReader<T> &r, uint8_t *dst, uint32_t &pos_io,
+                                                     uint32_t cap, const uint16_t *lit,
+                                                     const uint16_t *dist, int lig, uint32_t stop_bits = 0) {
   typedef CompactFmt F;
   constexpr uint32_t NONE = 0xffffffffu;
   uint32_t pos = pos_io;
-  bool     ok  = false;
+  int      ok  = COMPACT_FAIL;
   // The first T bytes of a non-overlapping match are loaded when the match is
   // decoded and stored when the next match starts (or the block ends), so the
   // load latency overlaps with the decode of the symbols in between.  Issue order
   // keeps it exact: the pending store is issued before any later load.
   uint32_t pend_off = NONE, pend_val = 0;
   for (;;) {
+    if (BOUNDED && r.ipos * 8u - r.n >= stop_bits) {
+      ok = COMPACT_STOP;
+      break;
+    }
     rd_fill(r);
     uint32_t b = (uint32_t)r.bits;
     uint32_t e = lit[b & ((1u << F::LIT_BITS) - 1u)];
@@ -784,7 +794,7 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
     if (!(e & F::F_BASE)) {                        // end of block, or no code
       if (e) {
         rd_drop(r, cl);
-        ok = true;
+        ok = COMPACT_END;
       }
       break;
     }
@@ -854,10 +864,12 @@ __device__ __forceinline__ bool huffman_block_compact(FastReader<T> &r, uint8_t 
 //   7. resolve   pointer jumping until every link ends at a literal or before
 //                the group, then the bytes are written out (coalesced), those
 //                from before the group fetched on the way.
-// The next round starts where the last lane of the true chain stopped.  Anything
-// unusual (malformed data on the true chain, output capacity, chains longer
-// than the link buffer) returns false and the stream is decoded again by the
-// serial passes, so this function only has to be right when it succeeds.
+// The next round starts where the last lane of the true chain stopped.  Where a
+// sub-sequence holds more bytes than the link buffer takes (very long matches)
+// a stretch of the block is decoded symbol by symbol instead (serial_stretch).
+// Malformed data on the true chain or output capacity reached returns false
+// and the stream is decoded again by the serial passes (they own the exact
+// failure result), so this function only has to be right when it succeeds.
 // ---------------------------------------------------------------------------
 #ifndef DEFL_PAR_S
 #define DEFL_PAR_S 256
@@ -873,6 +885,7 @@ constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane over this many by
 #define DEFL_PAR_MAX_FIXUP 16
 #endif
 constexpr int      PAR_MAX_FIXUP = DEFL_PAR_MAX_FIXUP;   // counting scans per round before the round is cut short
+constexpr uint32_t PAR_STRETCH  = 2048;              // input bits of a serial stretch (doubled while they follow each other)
 constexpr int      PAR_U        = 4;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
@@ -1098,7 +1111,29 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
   uint32_t       guard      = total_bits + 8u;       // every round consumes at least one bit
   bool           done       = false;
   uint32_t       quarter    = 10;                    // steps per quarter of a chain, adapted per round
+  uint32_t       boost      = 0;                     // serial stretches in a row (each twice as long as the one before)
   PROF_DECL;
+
+  // Very long matches (runs, repeated records) give a sub-sequence more bytes than the link
+  // buffer takes.  Such a stretch of the block is decoded one symbol after the other by the whole
+  // wavefront (64 lanes per match copy: what suits that data), from bit position `from` up to a
+  // symbol boundary some PAR_STRETCH bits on; the rounds go on behind it.  Sets B and `done`.
+  auto serial_stretch = [&](uint32_t from) -> bool {
+    PROF_BAIL(28);
+    group_sync();
+    rd_seek(r, r.src + (from >> 3));
+    rd_fill(r);
+    rd_drop(r, from & 7u);
+    const uint32_t span = PAR_STRETCH << boost;
+    const int      res  = huffman_block_compact<64, true>(r, dst, pos, cap, lit, dist, lane,
+                                                          span < total_bits - from ? from + span : total_bits);
+    if (res == COMPACT_FAIL || rd_overrun(r)) return false;
+    boost = boost < 6u ? boost + 1u : boost;
+    B     = r.ipos * 8u - r.n;
+    done  = res == COMPACT_END;
+    group_sync();
+    return true;
+  };
 
   while (!done) {
     if (guard-- == 0) return false;
@@ -1196,8 +1231,8 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       return false;
     }
     if (why == 3 && first_stop < 8) {                // very long matches: the serial copy loops do better
-      PROF_BAIL(28);
-      return false;
+      if (!serial_stretch(B)) return false;
+      continue;
     }
     const uint32_t nact = cut ? trunc : first_stop < 64 ? first_stop + 1u : 64u;
     uint32_t       cum  = (uint32_t)lane < nact ? sc.nout : 0;
@@ -1211,12 +1246,17 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     // The round's output is produced in groups of up to 16 consecutive chains whose bytes fit
     // the link buffer; four lanes share a chain (one quarter each) while the links are written.
     uint32_t a = 0;
+    bool     stretched = false;
     while (a < nact) {
       const uint32_t base_cum = a ? wave_read(cum, a - 1u) : 0u;
       const bool     fits     = (uint32_t)lane >= a && (uint32_t)lane < nact && (uint32_t)lane < a + 16u &&
                             cum - base_cum <= (uint32_t)PAR_R;
       const uint32_t nch = (uint32_t)__popcll(__ballot(fits));
-      if (nch == 0) return false;                    // cannot happen: one chain always fits
+      if (nch == 0) {                                // a chain of more bytes than the link buffer takes
+        if (!serial_stretch(wave_read(start, a))) return false;
+        stretched = true;
+        break;
+      }
       const uint32_t total_out = wave_read(cum, a + nch - 1u) - base_cum;
       PROF_COUNT(3, nch);
 
@@ -1378,8 +1418,10 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       a += nch;
     }
 
-    B    = wave_read(sc.exit, nact - 1u);
-    done = why == 1;                                 // the end-of-block code has been consumed
+    if (stretched) continue;                         // (B and done are set)
+    boost = 0;
+    B     = wave_read(sc.exit, nact - 1u);
+    done  = why == 1;                                // the end-of-block code has been consumed
   }
   PROF_FLUSH;
   pos_io = pos;
@@ -1421,13 +1463,16 @@ __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uin
         fixed_ready = false;
         rc = setup_dynamic<T, F>(r, L, lig, gshift);
       }
+#ifdef DEFL_PAR_PROFILE
+      if (SYM == 2 && rc == INFL_D_NOFIT && lig == 0) atomicAdd(&g_par_prof[15], 1ull);   // tables too large for the compact format
+#endif
       if (rc == INFL_D_OK) {
         if constexpr (SYM == 2) {
           rc = huffman_block_parallel(r, dst, pos, cap, L.lit, L.dist, *par, lig) ? INFL_D_OK
                                                                                    : INFL_D_NOFIT;
         } else if constexpr (SYM == 1) {
-          rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, lig) ? INFL_D_OK
-                                                                                   : INFL_D_NOFIT;
+          rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, lig) == COMPACT_END ? INFL_D_OK
+                                                                                              : INFL_D_NOFIT;
         } else {
           rc = huffman_block<T, F>(r, dst, pos, cap, L, lig, fuel);
         }
@@ -1629,8 +1674,8 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
 // variant 0: reference-geometry tables only (one launch).
 // variant 1: compact tables first, reference-geometry tables for what they defer (two launches).
 // variant 2: wavefront-parallel block decode first (one wavefront per stream); what it defers
-//            (data whose codes re-synchronise badly, very long matches, anything unusual) goes
-//            through the two serial passes of variant 1 (three launches).
+//            (anything malformed or out of space, tables too large for the compact format,
+//            tiny streams) goes through the two serial passes of variant 1 (three launches).
 // variant 3: diagnostic: the parallel pass alone; deferred streams keep INFL_STATUS_DEFERRED.
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,

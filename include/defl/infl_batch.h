@@ -111,9 +111,10 @@ infl_gpu_set_lanes_per_stream(int lanes);
        the first one could not finish;
    2 = (default) a first launch in which a whole wavefront decodes each
        Huffman block in parallel (64 speculative sub-sequences that
-       re-synchronise, matches resolved in LDS), then the two launches of 1 for
-       the streams it hands over: codes that do not re-synchronise, runs of
-       very long matches, anything malformed.
+       re-synchronise, matches resolved in LDS; stretches of very long matches
+       symbol by symbol), then the two launches of 1 for the streams it hands
+       over: anything malformed or out of space, tables too large for the
+       16-bit format, streams of fewer than 8 bytes.
    Returns the value in effect. */
 UNZ_EXPORT int
 infl_gpu_set_table_variant(int variant);

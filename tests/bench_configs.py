@@ -67,7 +67,7 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="stored,fixed,mixed,runs,noisy,pngdev,host,png")
+    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,noisy,pngdev,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
@@ -107,6 +107,19 @@ def main():
         comps = [wl.deflate(x) for x in raws]
         r = run_device(eng, oracle, comps, [65536] * 64, 1, 5, int(1024 * args.scale))
         print(json.dumps({"config": "byte runs (ratio %.4f)" % (sum(map(len, comps)) / (64 * 65536.0)), **r}), flush=True)
+    if "textruns" in which:
+        # ordinary text with runs spliced in (flat image areas, padding, repeated records in real files)
+        rng = np.random.default_rng(11)
+        raws = []
+        for i in range(256):
+            t = bytearray(wl.text_stream(i))
+            for _ in range(int(rng.integers(0, 4))):
+                at, n = int(rng.integers(0, 60000)), int(rng.integers(300, 5000))
+                t[at:at + n] = bytes([int(rng.integers(0, 256))]) * n
+            raws.append(bytes(t))
+        comps = [wl.deflate(x) for x in raws]
+        r = run_device(eng, oracle, comps, [65536] * 256, 1, 5, int(256 * args.scale))
+        print(json.dumps({"config": "text with runs spliced in (ratio %.3f)" % (sum(map(len, comps)) / (256 * 65536.0)), **r}), flush=True)
     if "noisy" in which:
         # barely compressible: 6 random bits per byte, almost all literals with ~6-bit codes
         rng = np.random.default_rng(8)

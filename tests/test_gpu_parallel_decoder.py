@@ -60,6 +60,33 @@ def test_long_matches_hit_the_byte_cap(engine, oracle):
     _check_batch(engine, oracle, streams, [len(r) for r in raws], 1, 16, "runs", 2)
 
 
+def _text_with_runs(rng, size, runs):
+    t = bytearray(_corpus(rng, size))
+    for _ in range(runs):
+        at, n = rng.randrange(0, max(1, size - 10)), rng.randint(300, 9000)
+        t[at:at + n] = bytes([rng.randrange(256)]) * min(n, size - at)
+    return bytes(t)
+
+
+def test_serial_stretches_inside_text(engine, oracle):
+    """Very long matches inside ordinary text: the parallel decoder has those stretches decoded
+    symbol by symbol and goes on behind them.  Stretches at the start, in the middle, at the
+    end of a block, several in a row (a run far longer than one stretch), output capacity and
+    input ending inside a stretch."""
+    rng = random.Random(18)
+    raws = [_text_with_runs(rng, 70000, k) for k in (1, 2, 3, 5, 8)]
+    raws += [bytes(5000) + _corpus(rng, 30000), _corpus(rng, 30000) + bytes(40000),
+             _corpus(rng, 4000) + bytes(300000) + _corpus(rng, 4000), bytes(200000)]
+    streams = [wl.deflate(r, lvl) for r in raws for lvl in (6, 9)]
+    caps = [len(r) for r in raws for _ in (6, 9)]
+    _check_batch(engine, oracle, streams, caps, 1, 16, "stretches", 2)
+    comp = wl.deflate(raws[7])
+    out_caps = [0, 1, 3999, 4000, 4001, 4258, 5000, 70000, 304000 - 1, 307999, 308000]
+    _check_batch(engine, oracle, [comp] * len(out_caps), out_caps, 1, 16, "stretch caps", 2)
+    cuts = sorted(set(range(1, len(comp), max(1, len(comp) // 97))))
+    _check_batch(engine, oracle, [comp[:k] for k in cuts], [len(raws[7])] * len(cuts), 1, 16, "stretch cuts", 2)
+
+
 def test_codes_that_do_not_resynchronise(engine, oracle):
     rng = np.random.default_rng(14)
     raws = [bytes(rng.integers(32, 32 + (1 << k), 30000 + 1000 * k, dtype=np.uint8)) for k in (1, 2, 3, 4, 5, 6, 7)]

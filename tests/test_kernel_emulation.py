@@ -106,3 +106,22 @@ def test_emulated_parallel_decoder_corner_shapes(oracle):
     _compare(oracle, [comp] * len(out_caps), out_caps, 1, 64, 2)
     cuts = [1, 2, 7, 8, 9, 40, 300, 301, len(comp) // 2, len(comp) - 5, len(comp) - 1]
     _compare(oracle, [comp[:k] for k in cuts], [len(text)] * len(cuts), 1, 64, 2)
+
+
+def test_emulated_parallel_decoder_serial_stretches(oracle):
+    """Very long matches inside text (variant 2): stretches decoded symbol by symbol inside the
+    parallel decoder, the rounds going on behind them; capacity and input ending inside one."""
+    rng = random.Random(80)
+    text = bytearray(wl.text_stream(9, 20000))
+    for at, n in ((0, 2500), (7000, 6000), (16000, 4000)):
+        text[at:at + n] = bytes([rng.randrange(256)]) * n
+    text = bytes(text)
+    long_run = wl.text_stream(10, 1500) + bytes(120000) + wl.text_stream(11, 1500)
+    streams = [wl.deflate(text), wl.deflate(text, 9), wl.deflate(long_run), wl.deflate(bytes(30000))]
+    caps = [len(text), len(text), len(long_run), 30000]
+    _compare(oracle, streams, caps, 1, 64, 2)
+    comp = wl.deflate(long_run)
+    out_caps = [0, 1499, 1500, 1501, 1758, 60000, len(long_run) - 1]
+    _compare(oracle, [comp] * len(out_caps), out_caps, 1, 64, 2)
+    cuts = list(range(1, len(comp), max(1, len(comp) // 12)))
+    _compare(oracle, [comp[:k] for k in cuts], [len(long_run)] * len(cuts), 1, 64, 2)

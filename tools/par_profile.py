@@ -71,7 +71,8 @@ def main():
         assert fn(buf) == 0
         _, st3, _, _ = b.results(want_dst=False)
         print("handed over to the serial passes: %d of %d streams" % (int((st3 != 0).sum()), len(st3)))
-        print("  blocks handed over because: very long matches %d, malformed %d" % (buf[28], buf[29]))
+        print("  blocks handed over because: tables too large for the compact format %d, malformed %d; "
+              "serial stretches inside the parallel pass %d" % (buf[15], buf[29], buf[28]))
         eng.lib.infl_gpu_set_table_variant(2)
     # (streams handed to the serial passes do not flush their counters: the shares describe the others)
     tot = v[:10].sum()
