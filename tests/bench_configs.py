@@ -67,7 +67,7 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,noisy,pngdev,host,png")
+    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,small,files,noisy,pngdev,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
@@ -120,6 +120,28 @@ def main():
         comps = [wl.deflate(x) for x in raws]
         r = run_device(eng, oracle, comps, [65536] * 256, 1, 5, int(256 * args.scale))
         print(json.dumps({"config": "text with runs spliced in (ratio %.3f)" % (sum(map(len, comps)) / (256 * 65536.0)), **r}), flush=True)
+    if "small" in which:
+        # many small streams (HTTP payloads, small images): per-stream and per-block costs dominate
+        for size in (1024, 4096, 16384):
+            raws = [wl.text_stream(5000 + i, size) for i in range(512)]
+            comps = [wl.deflate(x) for x in raws]
+            r = run_device(eng, oracle, comps, [size] * 512, 1, 5, int((64 << 20) // size // 512 * 4 * args.scale))
+            print(json.dumps({"config": "text streams of %d bytes" % size, **r}), flush=True)
+    if "files" in which:
+        # 64 KiB slices of binaries, libraries and scripts found on this machine, zlib level 6
+        import glob
+        paths = [p for pat in ("/usr/bin/python3*", "/usr/lib/x86_64-linux-gnu/libc.so*",
+                               "/usr/lib/x86_64-linux-gnu/libstdc++.so*", "/usr/lib/python3.10/*.py", "/usr/bin/gcc*")
+                 for p in sorted(glob.glob(pat)) if os.path.isfile(p)]
+        raws = []
+        for pth in paths:
+            data = open(pth, "rb").read(1 << 21)
+            raws += [data[o:o + 65536] for o in range(0, len(data) - 65535, 65536)]
+        raws = raws[:512]
+        comps = [wl.deflate(x) for x in raws]
+        r = run_device(eng, oracle, comps, [65536] * len(raws), 1, 5, max(1, int(65536 // len(raws) * args.scale)))
+        print(json.dumps({"config": "64 KiB slices of %d local binaries and scripts (ratio %.3f)"
+                          % (len(paths), sum(map(len, comps)) / (65536.0 * len(raws))), **r}), flush=True)
     if "noisy" in which:
         # barely compressible: 6 random bits per byte, almost all literals with ~6-bit codes
         rng = np.random.default_rng(8)
