@@ -262,7 +262,8 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
     if (!ok) return -1;
     if (infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p,
                           flags, n, (int32_t *)w.status.p, (uint32_t *)w.outlen.p,
-                          (int32_t *)w.detail.p, (uint32_t *)w.inpos.p, g_lanes, g_variant, w.hdst.p, st) != 0)
+                          detail ? (int32_t *)w.detail.p : nullptr, inpos ? (uint32_t *)w.inpos.p : nullptr,
+                          g_lanes, g_variant, w.hdst.p, st) != 0)
       return -1;
     ok &= hipMemcpyAsync(status, w.status.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
     ok &= hipMemcpyAsync(outlen, w.outlen.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
@@ -348,7 +349,8 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
     ok &= hipStreamWaitEvent(st, pp.evu[nsl], 0) == hipSuccess;
     ok = ok && infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p + lo, w.dst.p, (const uint64_t *)w.doff.p + lo,
                                  flags, hi - lo, (int32_t *)w.status.p + lo, (uint32_t *)w.outlen.p + lo,
-                                 (int32_t *)w.detail.p + lo, (uint32_t *)w.inpos.p + lo, g_lanes, g_variant,
+                                 detail ? (int32_t *)w.detail.p + lo : nullptr,
+                                 inpos ? (uint32_t *)w.inpos.p + lo : nullptr, g_lanes, g_variant,
                                  w.hdst.p, st) == 0;
     const size_t cnt = (hi - lo) * 4;
     ok &= hipMemcpyAsync(hm + lo, (int32_t *)w.status.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;

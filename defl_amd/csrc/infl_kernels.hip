@@ -1102,7 +1102,11 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
   return it;
 }
 
-__device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
+// Returns INFL_D_OK; INFL_D_INVALID when the block certainly fails in the reference too (no such
+// code or a code past the end of the input on the true chain, a distance before the output
+// start, more output than capacity: the reason itself is not worked out here); INFL_D_NOFIT
+// when the stream has to be decoded by the serial passes.
+__device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
                                                     uint32_t cap, const uint16_t *lit,
                                                     const uint16_t *dist, ParLds &P, int lane) {
   uint32_t       pos        = pos_io;
@@ -1118,7 +1122,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
   // buffer takes.  Such a stretch of the block is decoded one symbol after the other by the whole
   // wavefront (64 lanes per match copy: what suits that data), from bit position `from` up to a
   // symbol boundary some PAR_STRETCH bits on; the rounds go on behind it.  Sets B and `done`.
-  auto serial_stretch = [&](uint32_t from) -> bool {
+  auto serial_stretch = [&](uint32_t from) -> bool {        // false: the stream fails
     PROF_BAIL(28);
     group_sync();
     rd_seek(r, r.src + (from >> 3));
@@ -1136,7 +1140,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
   };
 
   while (!done) {
-    if (guard-- == 0) return false;
+    if (guard-- == 0) return INFL_D_NOFIT;
     PROF_COUNT(0, 1);
 
     // stage the input of this round (coalesced, clamped inside the stream, zero padded)
@@ -1228,10 +1232,10 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
     const uint32_t why        = !cut && first_stop < 64 ? wave_read(sc.stop, first_stop) : 0u;
     if (why == 2) {                                  // malformed on the true chain
       PROF_BAIL(29);
-      return false;
+      return INFL_D_INVALID;
     }
     if (why == 3 && first_stop < 8) {                // very long matches: the serial copy loops do better
-      if (!serial_stretch(B)) return false;
+      if (!serial_stretch(B)) return INFL_D_INVALID;
       continue;
     }
     const uint32_t nact = cut ? trunc : first_stop < 64 ? first_stop + 1u : 64u;
@@ -1240,7 +1244,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
       uint32_t t = wave_read(cum, (uint32_t)lane >= dlt ? lane - dlt : 0);
       if ((uint32_t)lane >= dlt) cum += t;
     }
-    if (wave_read(cum, nact - 1u) > cap - pos) return false;
+    if (wave_read(cum, nact - 1u) > cap - pos) return INFL_D_INVALID;   // more output than capacity
     PROF_MARK(3);
 
     // The round's output is produced in groups of up to 16 consecutive chains whose bytes fit
@@ -1253,7 +1257,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
                             cum - base_cum <= (uint32_t)PAR_R;
       const uint32_t nch = (uint32_t)__popcll(__ballot(fits));
       if (nch == 0) {                                // a chain of more bytes than the link buffer takes
-        if (!serial_stretch(wave_read(start, a))) return false;
+        if (!serial_stretch(wave_read(start, a))) return INFL_D_INVALID;
         stretched = true;
         break;
       }
@@ -1308,7 +1312,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
           }
         }
       }
-      if (__ballot(bad)) return false;
+      if (__ballot(bad)) return INFL_D_INVALID;
       group_sync();
       PROF_MARK(4);
 
@@ -1428,7 +1432,7 @@ __device__ __forceinline__ bool huffman_block_parallel(FastReader<64> &r, uint8_
   rd_seek(r, r.src + (B >> 3));                      // put the serial reader behind the block
   rd_fill(r);
   rd_drop(r, B & 7u);
-  return true;
+  return INFL_D_OK;
 }
 
 // Block loop (infl.c:1063-1092).  SYM selects the symbol loop: 0 = huffman_block (any table
@@ -1461,15 +1465,20 @@ __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uin
         }
       } else {
         fixed_ready = false;
+#ifdef DEFL_PAR_PROFILE
+        const uint64_t setup_t0 = __builtin_readcyclecounter();
+#endif
         rc = setup_dynamic<T, F>(r, L, lig, gshift);
+#ifdef DEFL_PAR_PROFILE
+        if (SYM == 2 && lig == 0) atomicAdd(&g_par_prof[14], (unsigned long long)(__builtin_readcyclecounter() - setup_t0));
+#endif
       }
 #ifdef DEFL_PAR_PROFILE
       if (SYM == 2 && rc == INFL_D_NOFIT && lig == 0) atomicAdd(&g_par_prof[15], 1ull);   // tables too large for the compact format
 #endif
       if (rc == INFL_D_OK) {
         if constexpr (SYM == 2) {
-          rc = huffman_block_parallel(r, dst, pos, cap, L.lit, L.dist, *par, lig) ? INFL_D_OK
-                                                                                   : INFL_D_NOFIT;
+          rc = huffman_block_parallel(r, dst, pos, cap, L.lit, L.dist, *par, lig);
         } else if constexpr (SYM == 1) {
           rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, lig) == COMPACT_END ? INFL_D_OK
                                                                                               : INFL_D_NOFIT;
@@ -1653,8 +1662,15 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
                                          (uint32_t)(d1 - d0), (flags & 0xff) == 1, lds[group],
                                          nullptr, lig, gshift, out, pos, cur);
   if ((MODE == 1 || MODE == 3 || MODE == 4) && rc != INFL_D_OK) {
-    if (lig == 0) status[i] = INFL_STATUS_DEFERRED;
-    return;
+    // The parallel pass reports a stream that certainly fails by itself when the caller wants
+    // the reference's result only (UNZ_ERR and the output position infl() leaves, which does not
+    // depend on why or where the stream failed); the reason, the input position and the
+    // position reached are worked out by the serial passes.
+    const bool exact = detail != nullptr || inpos != nullptr || (flags & INFL_F_PROGRESS);
+    if (MODE != 3 || exact || rc == INFL_D_NOFIT || rc == INFL_D_INTERNAL) {
+      if (lig == 0) status[i] = INFL_STATUS_DEFERRED;
+      return;
+    }
   }
   const uint32_t produced = ((flags & INFL_F_PROGRESS) && rc != INFL_D_OK && rc != INFL_D_INVALID) ? pos : out;
   if (lig == 0) {

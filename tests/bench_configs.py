@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import workloads as wl  # noqa: E402
 
 
-def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5):
+def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5, failing=0):
     import torch
     dev = torch.device("cuda", 0)
     n = len(comps) * tile
@@ -48,12 +48,14 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5):
                                       d_st.data_ptr(), d_ol.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     step()
     torch.cuda.synchronize()
-    assert bool((d_st == 0).all())
     k = min(len(comps), 128)
     s, so, do = wl.pack(comps[:k], raws_len[:k])
-    want, _, wol = oracle.infl_batch(s, so, do, flags, 8)
+    want, wst, wol = oracle.infl_batch(s, so, do, flags, 8)
+    assert np.array_equal(d_st[:k].cpu().numpy(), wst) and int((d_st != 0).sum()) == failing * tile
     got = d_dst[: int(do[-1])].cpu().numpy()
-    assert np.array_equal(got, want[: int(do[-1])]), "differs from the oracle"
+    for i in range(k):
+        a, m = int(do[i]), int(wol[i])
+        assert np.array_equal(got[a:a + m], want[a:a + m]), "differs from the oracle"
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     for a, b in ev:
         a.record(); step(); b.record()
@@ -67,7 +69,7 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,small,files,noisy,pngdev,host,png")
+    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,truncated,small,files,noisy,pngdev,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
@@ -120,6 +122,17 @@ def main():
         comps = [wl.deflate(x) for x in raws]
         r = run_device(eng, oracle, comps, [65536] * 256, 1, 5, int(256 * args.scale))
         print(json.dumps({"config": "text with runs spliced in (ratio %.3f)" % (sum(map(len, comps)) / (256 * 65536.0)), **r}), flush=True)
+    if "truncated" in which:
+        # the headline text batch with one stream in 64 cut off in its last quarter (a damaged file in
+        # the batch): those streams fail, the batch must not wait for them
+        raws = [wl.text_stream(i) for i in range(256)]
+        comps = [wl.deflate(x) for x in raws]
+        cut = [i for i in range(0, 256, 64)]
+        for i in cut:
+            comps[i] = comps[i][: len(comps[i]) * 7 // 8]
+        r = run_device(eng, oracle, comps, [65536] * 256, 1, 5, int(256 * args.scale), failing=len(cut))
+        r["decompressed_MB_per_s"] = round(r["decompressed_MB_per_s"] * (256 - len(cut)) / 256.0, 1)
+        print(json.dumps({"config": "64 KiB text streams, 1 in 64 truncated (rate over the intact ones)", **r}), flush=True)
     if "small" in which:
         # many small streams (HTTP payloads, small images): per-stream and per-block costs dominate
         for size in (1024, 4096, 16384):

@@ -67,13 +67,14 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
 extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
                               int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
                               uint32_t *inpos, int lanes, int variant, void *mirror) {
+  // (detail and inpos may be NULL: the caller then wants the reference's result only)
   if (variant >= 2) lanes = 64;   // the parallel pass is a 64-lane kernel; one group size per run here
   emu::g_lanes_per_group = lanes;
   return infl_launch_batch(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, variant,
                            mirror, nullptr);
 }
 
-// emu_run <in.bin> <out.bin> <lanes> <flags> <variant>
+// emu_run <in.bin> <out.bin> <lanes> <flags> <variant> [plain]
 //   in : u64 n, u64 src_off[n+1], u64 dst_off[n+1], src bytes
 //   out: i32 status[n], u32 outlen[n], i32 detail[n], u32 inpos[n], dst bytes
 // The arenas are allocated with their exact sizes so that AddressSanitizer sees any access
@@ -99,8 +100,10 @@ int main(int argc, char **argv) {
   // a second arena takes the copy every stream's output gets on its way to the host
   uint8_t *mirror = (uint8_t *)malloc(dof[n] ? dof[n] : 1);
   memset(mirror, 0x5a, dof[n] ? dof[n] : 1);
+  const bool plain = argc > 6 && atoi(argv[6]) != 0;   // no detail codes, no input positions asked for
   int rc = emu_infl_batch(src, so.data(), dst, dof.data(), atoi(argv[4]), n, status.data(), outlen.data(),
-                          detail.data(), inpos.data(), atoi(argv[3]), atoi(argv[5]), mirror);
+                          plain ? nullptr : detail.data(), plain ? nullptr : inpos.data(), atoi(argv[3]),
+                          atoi(argv[5]), mirror);
   if (rc != 0) return 3;
   for (uint64_t i = 0; i < n; i++) {                 // exactly the produced bytes, nothing around them
     const uint64_t a = dof[i], e = dof[i + 1];

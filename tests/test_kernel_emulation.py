@@ -125,3 +125,39 @@ def test_emulated_parallel_decoder_serial_stretches(oracle):
     _compare(oracle, [comp] * len(out_caps), out_caps, 1, 64, 2)
     cuts = list(range(1, len(comp), max(1, len(comp) // 12)))
     _compare(oracle, [comp[:k] for k in cuts], [len(long_run)] * len(cuts), 1, 64, 2)
+
+
+def test_emulated_parallel_pass_reports_certain_failures_itself(oracle):
+    """Without detail codes and input positions asked for, the parallel pass writes the result of
+    a stream that certainly fails (malformed, truncated, out of space) itself: same status and
+    output position as the oracle, nothing left marked for the serial passes."""
+    rng = random.Random(81)
+    text = wl.text_stream(12, 16000)
+    comp = wl.deflate(text)
+    runs = wl.deflate(wl.text_stream(13, 1000) + bytes(40000) + wl.text_stream(14, 1000))
+    streams, caps = [], []
+    for k in (5, 40, 700, len(comp) // 2, len(comp) - 3):
+        streams.append(comp[:k]); caps.append(len(text))
+    for c in (0, 1, 100, 5000, len(text) - 1):
+        streams.append(comp); caps.append(c)
+    for _ in range(24):
+        b = bytearray(comp)
+        b[rng.randrange(2, len(b))] ^= 1 << rng.randrange(8)
+        streams.append(bytes(b)); caps.append(len(text))
+    for k in (30, len(runs) // 2, len(runs) - 2):
+        streams.append(runs[:k]); caps.append(42000)
+    for c in (999, 1000, 1300, 30000, 41999):
+        streams.append(runs); caps.append(c)
+    streams += [comp, runs]; caps += [len(text), 42000]
+    src, src_off, dst_off = wl.pack(streams, caps)
+    want_dst, want_status, want_outlen = oracle.infl_batch(src, src_off, dst_off, 1)
+    dst, status, outlen, _, _ = emu_lib.run(src, src_off, dst_off, 1, 64, 2, plain=True)
+    assert (status == want_status).all() and (outlen == want_outlen).all()
+    assert (want_status != 0).sum() > 20 and (want_status == 0).sum() >= 2
+    for i in range(len(streams)):
+        a, n = int(dst_off[i]), int(outlen[i])
+        assert np.array_equal(dst[a:a + n], want_dst[a:a + n]), i
+    # variant 3 = the parallel pass alone: only what it cannot judge keeps the hand-over mark
+    _, st3, _, _, _ = emu_lib.run(src, src_off, dst_off, 1, 64, 3, plain=True)
+    assert ((st3 == want_status) | (st3 == 0x40000000)).all()
+    assert (st3 == 0x40000000).sum() <= 2, st3

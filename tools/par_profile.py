@@ -80,6 +80,8 @@ def main():
     print("streams %d; wave cycles per stream %.0f" % (n, tot / n))
     for k, name in enumerate(PHASES):
         print("  %-11s %6.2f %%  %9.0f cycles/stream" % (name, 100 * v[k] / tot, v[k] / n))
+    print("  %-11s %6.2f %%  %9.0f cycles/stream (dynamic block headers and table builds, outside the phases above)"
+          % ("block setup", 100 * v[14] / tot, v[14] / n))
     rounds = v[10]
     print("rounds/stream %.2f; rescans/round %.2f; sweeps/round %.2f; lanes/round %.1f"
           % (rounds / n, v[11] / rounds, v[12] / rounds, v[13] / rounds))
