@@ -25,6 +25,9 @@ extern "C" {
 /* status value the first (compact-table) pass leaves for a stream that the
    second pass has to decode; never visible to callers */
 #define INFL_STATUS_DEFERRED 0x40000000
+/* same, for a stream the parallel pass found to fail: only the last pass (tables in the
+   reference's geometry, exact failure result) needs to look at it */
+#define INFL_STATUS_DEFERRED_FAILING 0x40000001
 
 /* kernel flag bits: bit 0 = zlib wrapper; INFL_F_PROGRESS = when a stream stops
    for lack of input or output space, report the output position it reached in

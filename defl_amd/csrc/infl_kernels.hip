@@ -1604,9 +1604,10 @@ __device__ __forceinline__ void mirror_out(uint8_t *to, const uint8_t *from, uin
 // MODE 0: decode every stream and write its result.
 // MODE 1: first pass with the compact tables.  A stream that completes writes
 //         its result; any other stream is marked INFL_STATUS_DEFERRED.
-// MODE 2: second pass: only streams marked INFL_STATUS_DEFERRED are decoded.
+// MODE 2: last pass: only streams marked INFL_STATUS_DEFERRED or INFL_STATUS_DEFERRED_FAILING are decoded.
 // MODE 3: like MODE 1, but a whole wavefront decodes each Huffman block in parallel (T = 64).
-// MODE 4: like MODE 1, but only for streams marked INFL_STATUS_DEFERRED (by MODE 3).
+// MODE 4: like MODE 1, but only for streams marked INFL_STATUS_DEFERRED (by MODE 3; a stream it
+//         found to fail carries INFL_STATUS_DEFERRED_FAILING and waits for MODE 2).
 template <int T, class F, int MODE>
 __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const uint8_t *__restrict__ src,
                                                         const uint64_t *__restrict__ src_off,
@@ -1636,7 +1637,8 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
 
   if (i >= n) return;
   if (MODE == 2 || MODE == 4) {
-    const bool mine = status[i] == INFL_STATUS_DEFERRED;
+    const int32_t mark = status[i];
+    const bool    mine = mark == INFL_STATUS_DEFERRED || (MODE == 2 && mark == INFL_STATUS_DEFERRED_FAILING);
     group_sync();                                    // every lane has looked before one of them writes the result
     if (!mine) return;
   }
@@ -1667,8 +1669,9 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
     // depend on why or where the stream failed); the reason, the input position and the
     // position reached are worked out by the serial passes.
     const bool exact = detail != nullptr || inpos != nullptr || (flags & INFL_F_PROGRESS);
-    if (MODE != 3 || exact || rc == INFL_D_NOFIT || rc == INFL_D_INTERNAL) {
-      if (lig == 0) status[i] = INFL_STATUS_DEFERRED;
+    const bool undecided = MODE != 3 || rc == INFL_D_NOFIT || rc == INFL_D_INTERNAL;
+    if (undecided || exact) {
+      if (lig == 0) status[i] = undecided ? INFL_STATUS_DEFERRED : INFL_STATUS_DEFERRED_FAILING;
       return;
     }
   }

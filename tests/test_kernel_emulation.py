@@ -159,4 +159,4 @@ def test_emulated_parallel_pass_reports_certain_failures_itself(oracle):
     # variant 3 = the parallel pass alone: only what it cannot judge keeps the hand-over mark
     _, st3, _, _, _ = emu_lib.run(src, src_off, dst_off, 1, 64, 3, plain=True)
     assert ((st3 == want_status) | (st3 == 0x40000000)).all()
-    assert (st3 == 0x40000000).sum() <= 2, st3
+    assert (st3 == 0x40000000).sum() <= 2, st3        # (inputs of under 8 bytes go to the serial passes)
