@@ -1,7 +1,15 @@
-import json,sys
+#!/usr/bin/env python3
+"""One line per JSON result line of bench.py / tests/bench_configs.py output files: file, workload,
+decompressed MB/s, milliseconds.  `python tools/show_results.py file.jsonl [more ...]`"""
+import json
+import sys
+
 for f in sys.argv[1:]:
     for line in open(f):
-        line=line.strip()
-        if not line.startswith("{"): continue
-        d=json.loads(line)
-        print(f.split("/")[-1], (d.get("config") if isinstance(d.get("config"),str) else "headline text")[:40], d.get("decompressed_MB_per_s", d.get("value")), d.get("kernel_ms", d.get("ms_per_step")))
+        line = line.strip()
+        if not line.startswith("{"):
+            continue
+        d = json.loads(line)
+        name = d.get("config") if isinstance(d.get("config"), str) else "headline text"
+        print(f.split("/")[-1], name[:60], d.get("decompressed_MB_per_s", d.get("value")),
+              d.get("kernel_ms", d.get("ms_per_step", d.get("call_ms", d.get("infl_many_ms")))))
