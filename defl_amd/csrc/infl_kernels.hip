@@ -1108,7 +1108,8 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
 // when the stream has to be decoded by the serial passes.
 __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
                                                     uint32_t cap, const uint16_t *lit,
-                                                    const uint16_t *dist, ParLds &P, int lane) {
+                                                    const uint16_t *dist, ParLds &P, int lane,
+                                                    bool expect_short) {
   uint32_t       pos        = pos_io;
   uint32_t       B          = r.ipos * 8u - r.n;     // bit position of the block's first symbol
   const uint32_t total_bits = r.ilen * 8u;
@@ -1138,6 +1139,10 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
     group_sync();
     return true;
   };
+
+  // A stream of many short blocks (flush points every few bytes) would pay a whole round per
+  // block: after a short block the next one is tried symbol by symbol first.
+  if (expect_short && !serial_stretch(B)) return INFL_D_INVALID;
 
   while (!done) {
     if (guard-- == 0) return INFL_D_NOFIT;
@@ -1442,6 +1447,7 @@ __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uin
                                           StreamLds<F> &L, ParLds *par, int lig, int gshift,
                                           uint64_t &fuel) {
   bool     fixed_ready = false;
+  bool     short_block = false;                    // the Huffman block before this one took under 1024 input bits
   uint32_t bfinal = 0;
   while (!bfinal) {
     if (fuel-- == 0) return INFL_D_INTERNAL;
@@ -1478,7 +1484,9 @@ __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uin
 #endif
       if (rc == INFL_D_OK) {
         if constexpr (SYM == 2) {
-          rc = huffman_block_parallel(r, dst, pos, cap, L.lit, L.dist, *par, lig);
+          const uint32_t at = r.ipos * 8u - r.n;
+          rc = huffman_block_parallel(r, dst, pos, cap, L.lit, L.dist, *par, lig, short_block);
+          short_block = r.ipos * 8u - r.n - at < 1024u;
         } else if constexpr (SYM == 1) {
           rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, lig) == COMPACT_END ? INFL_D_OK
                                                                                               : INFL_D_NOFIT;

@@ -69,7 +69,7 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5, failing
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,truncated,small,files,noisy,pngdev,host,png")
+    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,truncated,flushed,small,files,noisy,pngdev,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
@@ -133,6 +133,23 @@ def main():
         r = run_device(eng, oracle, comps, [65536] * 256, 1, 5, int(256 * args.scale), failing=len(cut))
         r["decompressed_MB_per_s"] = round(r["decompressed_MB_per_s"] * (256 - len(cut)) / 256.0, 1)
         print(json.dumps({"config": "64 KiB text streams, 1 in 64 truncated (rate over the intact ones)", **r}), flush=True)
+    if "flushed" in which:
+        # the text workload with a flush point every 64..192 bytes (interactive protocols): some 500 tiny
+        # blocks per stream
+        import random
+        rng = random.Random(21)
+        raws = [wl.text_stream(i) for i in range(128)]
+        comps = []
+        for x in raws:
+            c, out, i = zlib.compressobj(6), [], 0
+            while i < len(x):
+                n = rng.randint(64, 192)
+                out.append(c.compress(x[i:i + n]) + c.flush(zlib.Z_SYNC_FLUSH))
+                i += n
+            comps.append(b"".join(out) + c.flush())
+        r = run_device(eng, oracle, comps, [65536] * 128, 1, 5, int(64 * args.scale))
+        print(json.dumps({"config": "64 KiB text streams flushed every 64..192 bytes (ratio %.3f)"
+                          % (sum(map(len, comps)) / (128 * 65536.0)), **r}), flush=True)
     if "small" in which:
         # many small streams (HTTP payloads, small images): per-stream and per-block costs dominate
         for size in (1024, 4096, 16384):

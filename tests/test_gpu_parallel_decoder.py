@@ -42,6 +42,28 @@ def test_many_blocks_per_stream(engine, oracle):
     _check_batch(engine, oracle, streams, [len(r) + 5 for r in raws], 1, 16, "flushed", 2)
 
 
+def test_streams_of_many_short_blocks(engine, oracle):
+    """Flush points every few bytes (interactive protocols): hundreds of tiny blocks per stream,
+    decoded symbol by symbol after the first one; long blocks in between go back to rounds."""
+    rng = random.Random(19)
+    streams, caps = [], []
+    for k in range(24):
+        raw = _corpus(rng, rng.randint(200, 30000))
+        c = zlib.compressobj(rng.choice([1, 6, 9]), zlib.DEFLATED, 15, 9,
+                             rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED]))
+        out, i = [], 0
+        while i < len(raw):
+            n = rng.randint(1, 120) if rng.random() < 0.9 else rng.randint(2000, 9000)
+            out.append(c.compress(raw[i:i + n]))
+            out.append(c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK, zlib.Z_PARTIAL_FLUSH])))
+            i += n
+        out.append(c.flush())
+        comp = b"".join(out)
+        streams += [comp, comp[: len(comp) * 2 // 3], comp]
+        caps += [len(raw), len(raw), len(raw) // 2]
+    _check_batch(engine, oracle, streams, caps, 1, 16, "short blocks", 2)
+
+
 def test_long_matches_hit_the_byte_cap(engine, oracle):
     rng = random.Random(13)
     raws = []

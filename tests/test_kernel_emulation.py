@@ -160,3 +160,23 @@ def test_emulated_parallel_pass_reports_certain_failures_itself(oracle):
     _, st3, _, _, _ = emu_lib.run(src, src_off, dst_off, 1, 64, 3, plain=True)
     assert ((st3 == want_status) | (st3 == 0x40000000)).all()
     assert (st3 == 0x40000000).sum() <= 2, st3        # (inputs of under 8 bytes go to the serial passes)
+
+
+def test_emulated_parallel_decoder_many_short_blocks(oracle):
+    """Flush points every few bytes: after a short block the next one is decoded symbol by
+    symbol inside the parallel decoder; a long block in between goes back to rounds."""
+    rng = random.Random(82)
+    text = wl.text_stream(15, 9000)
+    streams, caps = [], []
+    for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED):
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strat)
+        out, i = [], 0
+        while i < len(text):
+            n = rng.randint(1, 90) if i < 2500 or i > 7000 else 4000
+            out.append(c.compress(text[i:i + n]))
+            out.append(c.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK])))
+            i += n
+        comp = b"".join(out) + c.flush()
+        streams += [comp, comp[: len(comp) // 2], comp]
+        caps += [len(text), len(text), 3000]
+    _compare(oracle, streams, caps, 1, 64, 2)
