@@ -774,6 +774,11 @@ __device__ __forceinline__ int huffman_block_compact(FastReader<T> &r, uint8_t *
   // load latency overlaps with the decode of the symbols in between.  Issue order
   // keeps it exact: the pending store is issued before any later load.
   uint32_t pend_off = NONE, pend_val = 0;
+  // Runs (distance 1) repeat the byte before them: while that byte is known (a literal, or the
+  // run before) they are stored without the load, whose way through memory behind the stores
+  // in front of it is what a match costs here.
+  uint32_t last = 0;
+  bool     last_known = false;
   for (;;) {
     if (BOUNDED && r.ipos * 8u - r.n >= stop_bits) {
       ok = COMPACT_STOP;
@@ -788,6 +793,8 @@ __device__ __forceinline__ int huffman_block_compact(FastReader<T> &r, uint8_t *
       if (pos >= cap) break;
       rd_drop(r, cl);
       if (lig == 0) dst[pos] = (uint8_t)(e >> 4);
+      last       = (e >> 4) & 0xffu;
+      last_known = true;
       pos++;
       continue;
     }
@@ -815,15 +822,21 @@ __device__ __forceinline__ int huffman_block_compact(FastReader<T> &r, uint8_t *
     if (pend_off != NONE) dst[pend_off] = (uint8_t)pend_val;
     pend_off = NONE;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (d >= len) {
+    if (d == 1) {                                  // a run of the byte before it
+      if (!last_known) last = dst[pos - 1];
+      last_known = true;
+      for (uint32_t k = lig; k < len; k += T) dst[pos + k] = (uint8_t)last;
+    } else if (d >= len) {
       const uint8_t *sp = dst + (pos - d);
       if ((uint32_t)lig < len) {
         pend_val = sp[lig];
         pend_off = pos + lig;
       }
       for (uint32_t k = lig + T; k < len; k += T) dst[pos + k] = sp[k];
+      last_known = false;
     } else {
       coop_match<T>(dst, pos, d, len, lig);
+      last_known = false;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     pos += len;

@@ -51,7 +51,7 @@ def test_emulated_kernel_on_fixtures(oracle, lanes, variant):
             assert s == 0, n
 
 
-@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (8, 1), (32, 1), (64, 2)])
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (8, 1), (64, 2)])
 def test_emulated_kernel_on_header_cases(oracle, lanes, variant):
     streams = header_cases()
     _compare(oracle, streams, [4096] * len(streams), 0, lanes, variant)
