@@ -690,6 +690,7 @@ __device__ __forceinline__ int stored_block(R &r, uint8_t *dst, uint32_t &pos, u
   if (rd_overrun(r)) return INFL_D_NEED_INPUT;
   const uint8_t *s = rd_byte_ptr(r);
   if ((size_t)(rd_end(r) - s) < len) return INFL_D_NEED_INPUT;
+  if (len == 0) return INFL_D_OK;                  // a flush point: the reader stands where it has to
   coop_copy<T>(dst + pos, s, len, lig);
   pos += len;
   rd_seek(r, s + len);
@@ -1154,8 +1155,21 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
   };
 
   // A stream of many short blocks (flush points every few bytes) would pay a whole round per
-  // block: after a short block the next one is tried symbol by symbol first.
-  if (expect_short && !serial_stretch(B)) return INFL_D_INVALID;
+  // block: after a short block the next one is tried symbol by symbol first, with the reader
+  // as it stands (at B); a block that ends inside the stretch leaves it where it has to be.
+  if (expect_short) {
+    PROF_BAIL(28);
+    const int res = huffman_block_compact<64, true>(r, dst, pos, cap, lit, dist, lane,
+                                                    PAR_STRETCH < total_bits - B ? B + PAR_STRETCH : total_bits);
+    if (res == COMPACT_FAIL || rd_overrun(r)) return INFL_D_INVALID;
+    if (res == COMPACT_END) {
+      pos_io = pos;
+      return INFL_D_OK;
+    }
+    boost = 1;
+    B     = r.ipos * 8u - r.n;
+    group_sync();
+  }
 
   while (!done) {
     if (guard-- == 0) return INFL_D_NOFIT;
