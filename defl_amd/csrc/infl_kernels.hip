@@ -899,7 +899,13 @@ constexpr uint32_t PAR_LANE_CAP = 1024;              // a lane over this many by
 #define DEFL_PAR_MAX_FIXUP 16
 #endif
 constexpr int      PAR_MAX_FIXUP = DEFL_PAR_MAX_FIXUP;   // counting scans per round before the round is cut short
-constexpr uint32_t PAR_STRETCH  = 2048;              // input bits of a serial stretch (doubled while they follow each other)
+#ifndef DEFL_PAR_STRETCH
+#define DEFL_PAR_STRETCH 2048
+#endif
+#ifndef DEFL_PAR_STRETCH_LANES
+#define DEFL_PAR_STRETCH_LANES 8                     // a byte cap within this many lanes of a round: serial stretch
+#endif
+constexpr uint32_t PAR_STRETCH  = DEFL_PAR_STRETCH;              // input bits of a serial stretch (doubled while they follow each other)
 constexpr int      PAR_U        = 4;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
@@ -1266,7 +1272,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
       PROF_BAIL(29);
       return INFL_D_INVALID;
     }
-    if (why == 3 && first_stop < 8) {                // very long matches: the serial copy loops do better
+    if (why == 3 && first_stop < DEFL_PAR_STRETCH_LANES) {                // very long matches: the serial copy loops do better
       if (!serial_stretch(B)) return INFL_D_INVALID;
       continue;
     }

@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=8192)
     ap.add_argument("--pool", type=int, default=256)
-    ap.add_argument("--workload", default="text", choices=["text", "noise", "fixed", "png", "mixed"])
+    ap.add_argument("--workload", default="text", choices=["text", "noise", "fixed", "png", "mixed", "files"])
     args = ap.parse_args()
     from defl_amd import capi
     eng = capi.load()
@@ -42,6 +42,19 @@ def main():
     elif args.workload == "png":
         caps = [len(wl.png_like(i)) for i in range(args.pool)]
         comps = [wl.deflate(wl.png_like(i)) for i in range(args.pool)]
+    elif args.workload == "files":
+        import glob
+        paths = [p for pat in ("/usr/bin/python3*", "/usr/lib/x86_64-linux-gnu/libc.so*",
+                               "/usr/lib/x86_64-linux-gnu/libstdc++.so*", "/usr/lib/python3.10/*.py", "/usr/bin/gcc*")
+                 for p in sorted(glob.glob(pat)) if os.path.isfile(p)]
+        raws = []
+        for pth in paths:
+            data = open(pth, "rb").read(1 << 21)
+            raws += [data[o:o + 65536] for o in range(0, len(data) - 65535, 65536)]
+        raws = raws[: args.pool]
+        args.pool = len(raws)
+        comps = [wl.deflate(x) for x in raws]
+        caps = [65536] * len(raws)
     elif args.workload == "mixed":
         rng = np.random.default_rng(5)
         caps = [int(x) for x in np.exp(rng.uniform(np.log(1024), np.log(262144), args.pool))]
@@ -49,7 +62,7 @@ def main():
     else:
         rng = np.random.default_rng(8)
         comps = [wl.deflate(bytes(rng.integers(32, 96, 65536, dtype=np.uint8))) for i in range(args.pool)]
-    if args.workload not in ("png", "mixed"):
+    if args.workload not in ("png", "mixed", "files"):
         caps = [bench.STREAM_BYTES] * len(comps)
     reps = (args.streams + args.pool - 1) // args.pool
     comps = (comps * reps)[: args.streams]
