@@ -11,35 +11,40 @@
 #include "hip/hip_runtime.h"
 
 namespace emu {
+// One barrier per collective.  Every lane of a group makes the same sequence of collective calls
+// (that is what lockstep means), so a per-thread call counter tells all of them which of a few
+// rotating buffers the call uses; a buffer is written again only after a later barrier has shown
+// that every lane is done reading it.
 struct Group {
   pthread_barrier_t     bar;
-  std::atomic<uint64_t> mask{0};
+  std::atomic<uint64_t> mask[3];
+  Group() { for (auto &m : mask) m.store(0); }
 };
-int g_slots[64];   // ds_bpermute exchange buffer, one slot per lane of the wavefront
-thread_local dim3   t_threadIdx, t_blockIdx;
-thread_local Group *t_group = nullptr;
-thread_local int    t_lane  = 0;
-int                 g_lanes_per_group = 64;
+int g_slots[2][64];   // ds_bpermute exchange buffers, one slot per lane of the wavefront
+thread_local dim3     t_threadIdx, t_blockIdx;
+thread_local Group   *t_group = nullptr;
+thread_local int      t_lane  = 0;
+thread_local unsigned t_ballots = 0, t_permutes = 0;
+int                   g_lanes_per_group = 64;
 
 void group_barrier() { pthread_barrier_wait(&t_group->bar); }
 
 uint64_t ballot(bool pred) {
-  if (pred) t_group->mask.fetch_or(1ull << t_lane);
+  const unsigned k = t_ballots++ % 3u;
+  // the buffer of the next ballot was last read two ballots ago: every lane has since arrived at
+  // the barrier of the ballot before this one, and none writes it before this ballot's barrier
+  if (t_lane % g_lanes_per_group == 0) t_group->mask[(k + 1u) % 3u].store(0);
+  if (pred) t_group->mask[k].fetch_or(1ull << t_lane);
   group_barrier();
-  uint64_t m = t_group->mask.load();
-  group_barrier();
-  if (t_lane % g_lanes_per_group == 0) t_group->mask.store(0);
-  group_barrier();
-  return m;
+  return t_group->mask[k].load();
 }
 
 // Every lane of the group publishes its value, then reads the addressed lane's.
 int bpermute(int byte_addr, int value) {
-  g_slots[t_lane] = value;
+  const unsigned k = t_permutes++ & 1u;          // (the other buffer may still be read by slower lanes)
+  g_slots[k][t_lane] = value;
   group_barrier();
-  int v = g_slots[(byte_addr >> 2) & 63];
-  group_barrier();
-  return v;
+  return g_slots[k][(byte_addr >> 2) & 63];
 }
 
 void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
@@ -54,6 +59,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
         t_blockIdx  = dim3(b);
         t_lane      = (int)t;
         t_group     = &groups[t / T];
+        t_ballots = t_permutes = 0;
         fn();
       });
     for (auto &x : th) x.join();

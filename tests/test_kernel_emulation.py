@@ -41,7 +41,10 @@ def _compare(oracle, streams, caps, flags, lanes, variant=0):
 
 @pytest.mark.parametrize("lanes,variant", [(64, 0), (8, 0), (16, 1), (32, 1), (64, 2)])
 def test_emulated_kernel_on_fixtures(oracle, lanes, variant):
-    names = [n for n in ALL if os.path.getsize(os.path.join(DATA, "compressed", n)) < 40000]
+    # (64 host threads per wavefront on a few cores: the 64-lane runs take the smaller files only;
+    #  the GPU tests run every file through every variant)
+    limit = 6000 if lanes == 64 else 40000
+    names = [n for n in ALL if os.path.getsize(os.path.join(DATA, "compressed", n)) < limit]
     streams = [_read("compressed", n) for n in names]
     caps = [(len(_read("raw", n)) + 1000) if os.path.exists(os.path.join(DATA, "raw", n)) else 70000
             for n in names]
@@ -69,7 +72,7 @@ def test_emulated_kernel_zlib_and_fuzz(oracle):
     _compare(oracle, good, [max(0, c - 1) for c in caps], 1, 64, 2)
     _compare(oracle, good, [max(0, c - 1) for c in caps], 1, 64)
     bad = []
-    for t in range(90):
+    for t in range(60):
         b = bytearray(rng.choice(good))
         if t % 3 == 0:
             b = b[:rng.randint(0, len(b))]
