@@ -9,6 +9,11 @@ oracle before a number is printed.
   png      4 096 PNG-like images (128x128 RGBA scanlines, zlib-6) fed as IDAT pieces with
            infl_include() and decoded with one infl_many() call (host path, PCIe inclusive)
   mixed    text streams with log-uniform sizes 1 KiB .. 256 KiB, sorted by size (config 5 shape)
+  runs, textruns, truncated, flushed, small, files, noisy, pngdev, host
+           what real batches hold besides clean text: byte runs, text with runs spliced in, a
+           damaged stream in 64, flush points every few bytes, streams of 1 / 4 / 16 KiB, slices of
+           local binaries and scripts, near fixed-length codes, PNG-like scanlines kept on the
+           device, host arenas through infl_batch()
 """
 import argparse
 import ctypes as C
