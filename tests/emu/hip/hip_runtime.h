@@ -20,6 +20,7 @@ enum { hipSuccess = 0 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 
 #define __device__
+#define __constant__ static
 #define __global__
 #define __shared__ static
 #define __forceinline__ inline
@@ -77,6 +78,27 @@ static inline uint32_t __brev(uint32_t v) {
   return __builtin_bswap32(v);
 }
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicAnd(uint32_t *p, uint32_t v) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
+// v_alignbyte_b32: bytes [s, s + 4) of the 8-byte value hi:lo (s taken modulo 4)
+static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) {
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (s & 3u)));
+}
+// v_perm_b32: every selector byte picks one of the 8 bytes of s0:s1 (0-3 from s1, 4-7 from s0); 12 gives 0x00,
+// above 12 gives 0xff, 8-11 replicate a sign bit (not used by the kernel)
+static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+  const uint64_t src = ((uint64_t)s0 << 32) | s1;
+  uint32_t out = 0;
+  for (int b = 0; b < 4; b++) {
+    const uint32_t k = (sel >> (8 * b)) & 0xffu;
+    uint32_t v;
+    if (k < 8) v = (uint32_t)(src >> (8 * k)) & 0xffu;
+    else if (k < 12) v = ((src >> (16 * (k - 8) + 15)) & 1u) ? 0xffu : 0u;
+    else v = k == 12 ? 0u : 0xffu;
+    out |= v << (8 * b);
+  }
+  return out;
+}
 static inline uint32_t atomicMax(uint32_t *p, uint32_t v) {
   uint32_t old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
   while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
