@@ -344,6 +344,16 @@ __device__ __forceinline__ bool rd_overrun(const FastReader<T> &r) {
   return (uint64_t)r.ipos * 8u - r.n > (uint64_t)r.ilen * 8u;
 }
 __device__ __forceinline__ bool rd_overrun(const Reader &) { return false; }
+// Bits of the reservoir that come from the input (the fast reader also counts the zero bits it
+// supplies past the end of the stream in n).  The reference tests its reservoir, which holds
+// real bits only, in several places of the dynamic block header (infl.c:915-978), most visibly
+// "at least 7 bits before every code-length symbol" whatever that symbol's own length is.
+__device__ __forceinline__ uint32_t rd_real(const Reader &r) { return r.n; }
+template <int T>
+__device__ __forceinline__ uint32_t rd_real(const FastReader<T> &r) {
+  const int64_t left = (int64_t)r.ilen * 8 - ((int64_t)r.ipos * 8 - (int64_t)r.n);
+  return left <= 0 ? 0u : left < (int64_t)r.n ? (uint32_t)left : r.n;
+}
 __device__ __forceinline__ const uint8_t *rd_end(const Reader &r) { return r.end; }
 
 template <class F>
@@ -604,7 +614,7 @@ constexpr int INFL_D_NOFIT = 100;   // valid so far, but the tables exceed the c
 template <int T, class F, class R>
 __device__ __forceinline__ int setup_dynamic(R &r, StreamLds<F> &L, int lig, int gshift) {
   rd_fill(r);
-  if (r.n < 14) return INFL_D_NEED_INPUT;
+  if (rd_real(r) < 14) return INFL_D_NEED_INPUT;
   uint32_t hlit  = ((uint32_t)r.bits & 31u) + 257u;
   uint32_t hdist = (((uint32_t)r.bits >> 5) & 31u) + 1u;
   uint32_t hclen = (((uint32_t)r.bits >> 10) & 15u) + 4u;
@@ -618,7 +628,7 @@ __device__ __forceinline__ int setup_dynamic(R &r, StreamLds<F> &L, int lig, int
   for (uint32_t i = 0; i < hclen; i++) {
     uint32_t sym = i < 3 ? 16u + i : (uint32_t)(order_tail >> (4 * (i - 3))) & 15u;
     rd_fill(r);
-    if (r.n < 3) return INFL_D_NEED_INPUT;
+    if (rd_real(r) < 3) return INFL_D_NEED_INPUT;
     packed |= (uint64_t)((uint32_t)r.bits & 7u) << (3 * sym);
     rd_drop(r, 3);
   }
@@ -633,7 +643,7 @@ __device__ __forceinline__ int setup_dynamic(R &r, StreamLds<F> &L, int lig, int
   uint32_t prev = 0;
   for (uint32_t i = 0; i < n;) {
     rd_fill(r);
-    if (r.n < 7) return INFL_D_NEED_INPUT;
+    if (rd_real(r) < 7) return INFL_D_NEED_INPUT;
     uint32_t e = ctab[(uint32_t)r.bits & 255u];
     if (!(e & 255u)) return INFL_D_INVALID;
     uint32_t sym = e >> 8;
@@ -643,7 +653,7 @@ __device__ __forceinline__ int setup_dynamic(R &r, StreamLds<F> &L, int lig, int
       prev = sym;
       i++;
     } else if (sym == 16) {
-      if (r.n < 2) return INFL_D_NEED_INPUT;
+      if (rd_real(r) < 2) return INFL_D_NEED_INPUT;
       if (i == 0) return INFL_D_INVALID;
       uint32_t rep = 3u + ((uint32_t)r.bits & 3u);
       rd_drop(r, 2);
@@ -651,14 +661,14 @@ __device__ __forceinline__ int setup_dynamic(R &r, StreamLds<F> &L, int lig, int
       if ((uint32_t)lig < rep) lens[i + lig] = (uint8_t)prev;   // rep <= 6 <= T
       i += rep;
     } else if (sym == 17) {
-      if (r.n < 3) return INFL_D_NEED_INPUT;
+      if (rd_real(r) < 3) return INFL_D_NEED_INPUT;
       uint32_t rep = 3u + ((uint32_t)r.bits & 7u);
       rd_drop(r, 3);
       if (i + rep > n) return INFL_D_INVALID;
       i += rep;
       prev = 0;
     } else {
-      if (r.n < 7) return INFL_D_NEED_INPUT;
+      if (rd_real(r) < 7) return INFL_D_NEED_INPUT;
       uint32_t rep = 11u + ((uint32_t)r.bits & 127u);
       rd_drop(r, 7);
       if (i + rep > n) return INFL_D_INVALID;
@@ -785,6 +795,9 @@ __device__ __forceinline__ int huffman_block_compact(FastReader<T> &r, uint8_t *
       ok = COMPACT_STOP;
       break;
     }
+    // a truncated stream whose zero padding happens to decode (a literal, a valid match) must not
+    // run on until the output is full: stop once the reservoir lies wholly behind the input
+    if (r.ipos > r.ilen + 8u) break;
     rd_fill(r);
     uint32_t b = (uint32_t)r.bits;
     uint32_t e = lit[b & ((1u << F::LIT_BITS) - 1u)];

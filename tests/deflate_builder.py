@@ -209,4 +209,8 @@ def header_cases():
         xb = 0 if dsym < 4 else (dsym >> 1) - 1
         syms2 += [("sym", 258, 0, 0), ("dist", dsym, (1 << xb) - 1 if xb else 0, xb)]
     cases.append(dynamic_block(deep2, ddeep, syms2))
+    # "at least 7 bits in the reservoir before every code-length symbol" (infl.c:947), whatever the
+    # symbol's own length: the input ends 6 bits (rejected) or more (accepted) before the last one
+    short7 = bytes.fromhex("05c0810c00000000307feb06")
+    cases += [short7, short7 + b"\x00", short7[:-1], short7 + b"\xff\xff"]
     return cases
