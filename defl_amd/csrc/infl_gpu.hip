@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -19,9 +20,8 @@
 
 namespace {
 
-std::mutex g_mu;            // guards the cached workspace below
-int        g_lanes = 16;    // lanes of a wavefront per stream
-int        g_variant = 2;   // 0 reference-geometry tables, 1 compact tables + deferred pass, 2 parallel first
+std::atomic<int> g_lanes{16};    // lanes of a wavefront per stream
+std::atomic<int> g_variant{2};   // 0 reference-geometry tables, 1 compact tables + deferred pass, 2 parallel first
 
 struct Buf {
   void  *p   = nullptr;
@@ -36,6 +36,7 @@ struct Workspace {
 };
 constexpr int MAX_DEV = 16;
 Workspace     g_ws[MAX_DEV];
+std::mutex    g_mu[MAX_DEV];   // one per device: host threads that drive different GPUs do not wait for each other
 
 // Streams and events of the sliced host-memory path (default priority), made on first use.
 constexpr int      kPipeSlices     = 16;               // at most this many slices per call
@@ -49,7 +50,7 @@ struct Pipe {
 };
 Pipe g_pipe[MAX_DEV];
 
-bool pipe_ready(int dev) {                             // caller holds g_mu
+bool pipe_ready(int dev) {                             // caller holds g_mu[dev]
   Pipe &p = g_pipe[dev];
   if (p.state) return p.state > 0;
   p.state = -1;
@@ -155,8 +156,8 @@ int infl_gpu_download(void *host_dst, const void *dev_src, size_t bytes) {
 int infl_gpu_sync(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : -1; }
 
 int infl_gpu_set_lanes_per_stream(int lanes) {
-  if (lanes == 64 || lanes == 32 || lanes == 16 || lanes == 8) g_lanes = lanes;
-  return g_lanes;
+  if (lanes == 64 || lanes == 32 || lanes == 16 || lanes == 8) g_lanes.store(lanes);
+  return g_lanes.load();
 }
 
 int infl_gpu_set_table_variant(int variant) {
@@ -165,8 +166,8 @@ int infl_gpu_set_table_variant(int variant) {
 #else
   constexpr int kMaxVariant = 2;
 #endif
-  if (variant >= 0 && variant <= kMaxVariant) g_variant = variant;
-  return g_variant;
+  if (variant >= 0 && variant <= kMaxVariant) g_variant.store(variant);
+  return g_variant.load();
 }
 
 int infl_batch_dev(const void *dev_src, const uint64_t *dev_src_off, void *dev_dst,
@@ -175,7 +176,7 @@ int infl_batch_dev(const void *dev_src, const uint64_t *dev_src_off, void *dev_d
   if (n == 0) return 0;
   if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen) return -1;
   return infl_launch_batch(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status,
-                           dev_outlen, nullptr, nullptr, g_lanes, g_variant, nullptr, hip_stream);
+                           dev_outlen, nullptr, nullptr, g_lanes.load(), g_variant.load(), nullptr, hip_stream);
 }
 
 // Same with the per-stream detail codes (INFL_D_*); for tests and diagnosis.
@@ -185,7 +186,7 @@ int infl_batch_dev_detail(const void *dev_src, const uint64_t *dev_src_off, void
   if (n == 0) return 0;
   if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen) return -1;
   return infl_launch_batch(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status,
-                           dev_outlen, dev_detail, nullptr, g_lanes, g_variant, nullptr, hip_stream);
+                           dev_outlen, dev_detail, nullptr, g_lanes.load(), g_variant.load(), nullptr, hip_stream);
 }
 
 static Buf  g_pin;                 // see infl_rt_pinned_acquire
@@ -213,8 +214,9 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
 
-  std::lock_guard<std::mutex> lock(g_mu);
+  std::lock_guard<std::mutex> lock(g_mu[dev]);
   Workspace &w = g_ws[dev];
+  const int lanes = g_lanes.load(), variant = g_variant.load();
   const size_t src_bytes = (size_t)src_off[n], dst_bytes = (size_t)dst_off[n];
   const size_t off_bytes = (n + 1) * sizeof(uint64_t);
 
@@ -246,7 +248,13 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
     const uint64_t b0 = dst_off[lo], b1 = dst_off[hi];
     for (size_t t = 1; t <= threads && lo < hi; t++) {
       const size_t cut = t < threads ? std::min(cut_at(b0 + (b1 - b0) / threads * t, lo), hi) : hi;
-      if (cut > lo) pool.emplace_back(scatter, lo, cut);
+      if (cut > lo) {
+        try {
+          pool.emplace_back(scatter, lo, cut);
+        } catch (...) {                                  // no thread to be had: this one does the share
+          scatter(lo, cut);
+        }
+      }
       lo = cut;
     }
   };
@@ -259,12 +267,18 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
     if (src_bytes) ok &= hipMemcpyAsync(w.src.p, src, src_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
     ok &= hipMemcpyAsync(w.soff.p, src_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
     ok &= hipMemcpyAsync(w.doff.p, dst_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
-    if (!ok) return -1;
+    if (!ok) {
+      (void)hipStreamSynchronize(st);
+      (void)hipGetLastError();
+      return -1;
+    }
     if (infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p,
                           flags, n, (int32_t *)w.status.p, (uint32_t *)w.outlen.p,
                           detail ? (int32_t *)w.detail.p : nullptr, inpos ? (uint32_t *)w.inpos.p : nullptr,
-                          g_lanes, g_variant, w.hdst.p, st) != 0)
+                          lanes, variant, w.hdst.p, st) != 0) {
+      (void)hipStreamSynchronize(st);                    // the uploads queued above still read the caller's buffers
       return -1;
+    }
     ok &= hipMemcpyAsync(status, w.status.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
     ok &= hipMemcpyAsync(outlen, w.outlen.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
     if (detail) ok &= hipMemcpyAsync(detail, w.detail.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
@@ -292,7 +306,11 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
   // about 7 GB/s, one seventh of the link); the result arrays come back through pinned
   // memory as well, so that no call here holds this thread until a slice's kernels are done.
   Pipe      &pp     = g_pipe[dev];
-  const bool staged = src != g_pin.p;                  // (the gather buffer of infl_rt_pinned_acquire is pinned already)
+  bool staged;                                         // (the gather buffer of infl_rt_pinned_acquire is pinned already)
+  {
+    std::lock_guard<std::mutex> pin_lock(g_pin_mu);
+    staged = src != g_pin.p;
+  }
   if (staged && !host_reserve(w.hsrc, src_bytes + 16)) return -12;
   const uint8_t *from = staged ? (const uint8_t *)w.hsrc.p : (const uint8_t *)src;
   uint32_t      *hm   = (uint32_t *)w.hmeta.p;
@@ -339,9 +357,16 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
           memcpy((uint8_t *)w.hsrc.p + s0 + a, (const uint8_t *)src + s0 + a, b - a);
         };
         const bool many = len >= (1u << 20);
-        for (int t = 1; t < T && many; t++) helper[t - 1] = std::thread(part, t);
+        for (int t = 1; t < T && many; t++) {
+          try {
+            helper[t - 1] = std::thread(part, t);
+          } catch (...) {
+            part(t);
+          }
+        }
         if (many) part(0); else memcpy((uint8_t *)w.hsrc.p + s0, (const uint8_t *)src + s0, len);
-        for (int t = 1; t < T && many; t++) helper[t - 1].join();
+        for (int t = 1; t < T && many; t++)
+          if (helper[t - 1].joinable()) helper[t - 1].join();
       }
       ok &= hipMemcpyAsync((uint8_t *)w.src.p + s0, from + s0, s1 - s0, hipMemcpyHostToDevice, pp.up) == hipSuccess;
     }
@@ -350,7 +375,7 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
     ok = ok && infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p + lo, w.dst.p, (const uint64_t *)w.doff.p + lo,
                                  flags, hi - lo, (int32_t *)w.status.p + lo, (uint32_t *)w.outlen.p + lo,
                                  detail ? (int32_t *)w.detail.p + lo : nullptr,
-                                 inpos ? (uint32_t *)w.inpos.p + lo : nullptr, g_lanes, g_variant,
+                                 inpos ? (uint32_t *)w.inpos.p + lo : nullptr, lanes, variant,
                                  w.hdst.p, st) == 0;
     const size_t cnt = (hi - lo) * 4;
     ok &= hipMemcpyAsync(hm + lo, (int32_t *)w.status.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;
