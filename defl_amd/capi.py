@@ -23,6 +23,7 @@ EXPORTS = [
     "infl_gpu_init", "infl_gpu_device_count", "infl_batch_dev", "infl_batch_dev_detail", "infl_batch",
     "infl_many", "infl_gpu_malloc", "infl_gpu_free", "infl_gpu_upload", "infl_gpu_download",
     "infl_gpu_sync", "infl_gpu_set_lanes_per_stream", "infl_gpu_set_table_variant",
+    "infl_batch_noalloc",
 ]
 
 
@@ -120,6 +121,7 @@ class Engine:
             "infl_batch_dev": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp]),
             "infl_batch_dev_detail": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp, vp]),
             "infl_batch": (i32, [vp, vp, vp, vp, i32, sz, vp, vp]),
+            "infl_batch_noalloc": (i32, [vp, vp, vp, vp, i32, sz, vp, vp]),
             "infl_many": (i32, [vp, sz, vp]),
             "infl_gpu_malloc": (vp, [sz]),
             "infl_gpu_free": (None, [vp]),

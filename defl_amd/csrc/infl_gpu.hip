@@ -50,6 +50,36 @@ struct Pipe {
 };
 Pipe g_pipe[MAX_DEV];
 
+// Staging of infl_batch_noalloc(): device memory behind the inputs and outputs of a host-memory
+// batch (source arena, destination arena, the two offset tables, the two result arrays), inside a
+// file-scope array of the code object instead of hipMalloc'ed buffers.  Every GPU the library runs
+// on holds its own copy of the array, at its own address, until the process ends; in host code the
+// array's name is only a handle for hipGetSymbolAddress, never a pointer a kernel could use.
+constexpr size_t kNaSrcBytes = INFL_NOALLOC_MAX_SRC + 64;             // (+ a little slack behind each arena)
+constexpr size_t kNaDstBytes = INFL_NOALLOC_MAX_DST + 64;
+constexpr size_t kNaOffBytes = (INFL_NOALLOC_MAX_STREAMS + 1) * sizeof(uint64_t);
+constexpr size_t kNaResBytes = INFL_NOALLOC_MAX_STREAMS * sizeof(uint32_t);
+constexpr size_t kNaSrcAt = 0, kNaDstAt = kNaSrcAt + kNaSrcBytes, kNaSoffAt = kNaDstAt + kNaDstBytes,
+                 kNaDoffAt = kNaSoffAt + kNaOffBytes, kNaStatusAt = kNaDoffAt + kNaOffBytes,
+                 kNaOutlenAt = kNaStatusAt + kNaResBytes, kNaTotal = kNaOutlenAt + kNaResBytes;
+static_assert(kNaSrcBytes % 64 == 0 && kNaDstBytes % 64 == 0 && kNaOffBytes % 8 == 0, "regions stay aligned");
+static __device__ __align__(256) unsigned char scratch[kNaTotal];
+
+unsigned char *g_scratch_ptr[MAX_DEV] = {};            // device address of `scratch` per device (under g_mu[dev])
+
+// Looks the array's address up on the current device (once per device); caller holds g_mu[dev].
+unsigned char *scratch_on(int dev) {
+  if (!g_scratch_ptr[dev]) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = (unsigned char *)p;
+  }
+  return g_scratch_ptr[dev];
+}
+
 bool pipe_ready(int dev) {                             // caller holds g_mu[dev]
   Pipe &p = g_pipe[dev];
   if (p.state) return p.state > 0;
@@ -127,7 +157,12 @@ int infl_gpu_init(int device) {
     (void)hipGetLastError();
     return -1;
   }
-  return hipFree(nullptr) == hipSuccess ? 0 : -1;    // forces context creation
+  if (hipFree(nullptr) != hipSuccess) return -1;     // forces context creation
+  if (device < MAX_DEV) {
+    std::lock_guard<std::mutex> lock(g_mu[device]);
+    if (!scratch_on(device)) return -1;
+  }
+  return 0;
 }
 
 void *infl_gpu_malloc(size_t bytes) {
@@ -394,6 +429,55 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
   }
   for (auto &th : pool) th.join();
   return ok && cuts[nsl] == n ? 0 : -1;
+}
+
+int infl_batch_noalloc(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
+                       int flags, size_t n, int32_t *status, uint32_t *outlen) {
+  if (n == 0) return 0;
+  if (!src_off || !dst_off || !status || !outlen) return -1;
+  const uint64_t src_bytes = src_off[n], dst_bytes = dst_off[n];
+  if (n > INFL_NOALLOC_MAX_STREAMS || src_bytes > INFL_NOALLOC_MAX_SRC || dst_bytes > INFL_NOALLOC_MAX_DST) {
+    fprintf(stderr, "defl: infl_batch_noalloc: %zu streams, %llu source and %llu destination bytes exceed the fixed "
+                    "workspace (%u streams, %u and %u bytes)\n", n, (unsigned long long)src_bytes,
+            (unsigned long long)dst_bytes, (unsigned)INFL_NOALLOC_MAX_STREAMS, (unsigned)INFL_NOALLOC_MAX_SRC,
+            (unsigned)INFL_NOALLOC_MAX_DST);
+    return -105;                                       // UNZ_EFULL
+  }
+  if ((src_bytes && !src) || (dst_bytes && !dst)) return -1;
+  if (!device_ready()) return -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
+
+  // Calls on one GPU share that GPU's array: the lock keeps host threads apart (a caller that
+  // bypasses it, e.g. from two processes' worth of streams, would race).  Nothing in the array
+  // has to start at zero: every stream's status, length and bytes are written by the kernels
+  // before they are read back, whatever the last call left behind.
+  std::lock_guard<std::mutex> lock(g_mu[dev]);
+  unsigned char *base = scratch_on(dev);
+  if (!base) return -1;
+  const size_t   off_bytes = (n + 1) * sizeof(uint64_t);
+  hipStream_t    st = nullptr;
+  bool ok = true;
+  if (src_bytes) ok &= hipMemcpyAsync(base + kNaSrcAt, src, src_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(base + kNaSoffAt, src_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(base + kNaDoffAt, dst_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok = ok && infl_launch_batch(base + kNaSrcAt, (const uint64_t *)(base + kNaSoffAt), base + kNaDstAt,
+                               (const uint64_t *)(base + kNaDoffAt), flags == 1 ? 1 : 0, n,
+                               (int32_t *)(base + kNaStatusAt), (uint32_t *)(base + kNaOutlenAt), nullptr, nullptr,
+                               g_lanes.load(), g_variant.load(), nullptr, st) == 0;
+  if (ok) {
+    ok &= hipMemcpyAsync(status, base + kNaStatusAt, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok &= hipMemcpyAsync(outlen, base + kNaOutlenAt, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    // the whole destination arena in one copy: behind a stream's outlen[i] bytes its share holds
+    // whatever the decoder left there (the reference leaves that part unspecified too)
+    if (dst_bytes) ok &= hipMemcpyAsync(dst, base + kNaDstAt, dst_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+  }
+  const bool drained = hipStreamSynchronize(st) == hipSuccess;
+  if (!ok || !drained) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return 0;
 }
 
 int infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,

@@ -77,6 +77,26 @@ infl_batch(const void *src, const uint64_t *src_off,
            int flags, size_t n, int32_t *status, uint32_t *outlen);
 
 /*
+ * infl_batch() for callers that cannot allocate: tight serving loops, harnesses that forbid
+ * hipMalloc, code that runs while a HIP graph is being captured elsewhere in the process.  It has
+ * no counterpart in the reference.  Same arguments and results as infl_batch(), but the device
+ * staging (source and destination arenas, offset tables, result arrays) is a fixed array inside
+ * the library's code object, one copy per GPU, held until the process ends; the call allocates and
+ * frees nothing.  Limits: n <= INFL_NOALLOC_MAX_STREAMS, src_off[n] <= INFL_NOALLOC_MAX_SRC,
+ * dst_off[n] <= INFL_NOALLOC_MAX_DST; beyond them the call returns UNZ_EFULL and decodes nothing.
+ * dst[dst_off[i] + outlen[i] .. dst_off[i + 1]) is unspecified afterwards (infl_batch() leaves it
+ * untouched).  Calls on the same GPU share one array: the library serialises host threads of one
+ * process on it; callers in different processes each have their own copy.
+ */
+#define INFL_NOALLOC_MAX_STREAMS 4096u
+#define INFL_NOALLOC_MAX_SRC     (4u << 20)
+#define INFL_NOALLOC_MAX_DST     (16u << 20)
+UNZ_EXPORT int
+infl_batch_noalloc(const void *src, const uint64_t *src_off,
+                   void *dst, const uint64_t *dst_off,
+                   int flags, size_t n, int32_t *status, uint32_t *outlen);
+
+/*
  * Deferred form of infl() for many streams that were filled with
  * infl_include(): gathers every stream's chunk list into one staging arena,
  * decodes all of them with one launch and stores each stream's result as
