@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: decompressed MB/s of a batch of 65 536 independent 64 KiB zlib streams
-(dynamic Huffman, level 6, synthetic English-like text) on N x MI355X, one launch per step.
+"""Headline benchmark: decompressed MB/s of a batch of independent zlib streams on N x MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--workload text64k|mixed]
 
-One process per GPU.  Streams are independent, so each rank decodes its own 65 536-stream
-shard with no data-path collective (weak scaling); RCCL only sums the per-rank result
-counters.  Inputs and outputs stay in HBM; a step is one pass of the hot path (one
-infl_batch_dev launch) over the rank's batch.  Prints ONE JSON line on rank 0.
+Workloads (synthetic Zipf text, zlib level 6, dynamic Huffman):
+  text64k  65 536 streams of 64 KiB (the configuration the metric is quoted on);
+  mixed    1 048 576 streams of 1 KiB .. 256 KiB, log-uniform (the sharded mixed-size configuration).
+Scaling:
+  weak     every GPU decodes a batch of the full size (default: per-GPU work fixed as N grows);
+  strong   ONE batch of the full size is cut into N contiguous ranges that balance the sum of
+           compressed + decompressed bytes (defl_amd.shard.partition), one range per GPU.
+One process per GPU, no data-path collective: streams are independent.  RCCL carries only the
+result counters and the per-rank times.  Inputs and outputs stay in HBM; a step is one pass of the
+hot path (one infl_batch_dev call) over the rank's streams.  Started without a launcher and with
+--gpus N > 1, the script starts `torch.distributed.run` itself (before it touches any GPU) and
+relays the result.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 from concurrent.futures import ThreadPoolExecutor
 import os
+import subprocess
 import sys
 import time
 
@@ -22,58 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import workloads as wl  # noqa: E402
+from defl_amd import shard  # noqa: E402
 
 STREAM_BYTES = 65536
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec), GB/s
-
-
-def _make_stream(i):
-    raw = wl.text_stream(i, STREAM_BYTES)
-    return wl.deflate(raw, 6, True)
-
-
-def build_pool(first, count, workers):
-    """Threads, not processes: a fork after the HIP runtime is up (a profiler preloads it before
-    main) can deadlock the children.  zlib and numpy release the GIL for most of the work."""
-    idx = list(range(first, first + count))
-    if workers > 1:
-        with ThreadPoolExecutor(workers) as pool:
-            return list(pool.map(_make_stream, idx))
-    return [_make_stream(i) for i in idx]
-
-
-def cpu_baseline(comps, oracle, threads, budget_s):
-    """The CPU oracle (a port of the reference's infl_buf path) timed on the host cores over
-    the same streams: `threads` threads with static partitioning, repeated until about
-    `budget_s` seconds of CPU-core time are spent."""
-    src, src_off, dst_off = wl.pack(comps, [STREAM_BYTES] * len(comps))
-    oracle.infl_batch(src, src_off, dst_off, 1, threads)            # warm-up (tables, pages)
-    reps, t_total, out_bytes = 0, 0.0, 0
-    while t_total * threads < budget_s and reps < 64:
-        t0 = time.perf_counter()
-        _, status, outlen = oracle.infl_batch(src, src_off, dst_off, 1, threads)
-        t_total += time.perf_counter() - t0
-        out_bytes += int(outlen.sum())
-        reps += 1
-        assert (status == 0).all()
-    t0 = time.perf_counter()
-    sub = max(1, len(comps) // 16)
-    s1, so1, do1 = wl.pack(comps[:sub], [STREAM_BYTES] * sub)
-    _, _, ol1 = oracle.infl_batch(s1, so1, do1, 1, 1)
-    t1 = time.perf_counter() - t0
-    import zlib
-    t0 = time.perf_counter()
-    zbytes = sum(len(zlib.decompress(c)) for c in comps[:sub])
-    tz = time.perf_counter() - t0
-    return {
-        "value": round(out_bytes / t_total / 1e6, 1),
-        "unit": "MB/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": "%d distinct streams of this workload x %d passes, %d threads; 1 thread: %.0f MB/s "
-                  "(system zlib, 1 thread: %.0f MB/s)"
-                  % (len(comps), reps, threads, int(ol1.sum()) / t1 / 1e6, zbytes / tz / 1e6),
-    }
+FULL_STREAMS = {"text64k": 65536, "mixed": 1048576}
 
 
 def note(msg):
@@ -82,22 +43,192 @@ def note(msg):
         print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
 
 
+def pool_sizes(workload, pool):
+    """Decompressed size of every distinct stream of the pool."""
+    if workload == "text64k":
+        return [STREAM_BYTES] * pool
+    rng = np.random.default_rng(5)
+    return [int(x) for x in np.exp(rng.uniform(np.log(1024), np.log(262144), pool))]
+
+
+def _make_stream(arg):
+    i, size = arg
+    return wl.deflate(wl.text_stream(i, size), 6, True)
+
+
+def build_pool(first, sizes, workers):
+    """Threads, not processes: a fork after the HIP runtime is up (a profiler preloads it before
+    main) can deadlock the children.  zlib and numpy release the GIL for most of the work."""
+    jobs = [(first + k, s) for k, s in enumerate(sizes)]
+    if workers > 1:
+        with ThreadPoolExecutor(workers) as ex:
+            return list(ex.map(_make_stream, jobs))
+    return [_make_stream(j) for j in jobs]
+
+
+def host_threads():
+    """Threads the CPU baseline may use: the cores this process is allowed on, capped by the
+    share the machine gives the job (OMP_NUM_THREADS, where the operator sets it)."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS", "")
+    if cap.isdigit() and int(cap) > 0:
+        allowed = min(allowed, int(cap))
+    return max(1, allowed)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(comps, sizes, oracle, threads, budget_s):
+    """The CPU oracle (a port of the reference's infl_buf path; the reference itself cannot be
+    built here) timed on the host cores over streams of the same workload: `threads` threads with
+    static partitioning, passes repeated until about `budget_s` seconds of core time are spent;
+    the value is the median pass.  One thread and the system's zlib are timed beside it."""
+    src, src_off, dst_off = wl.pack(comps, sizes)
+    oracle.infl_batch(src, src_off, dst_off, 1, threads)            # warm-up (tables, pages)
+    times, out_bytes = [], 0
+    while (sum(times) * threads < budget_s or len(times) < 3) and len(times) < 64:
+        t0 = time.perf_counter()
+        _, status, outlen = oracle.infl_batch(src, src_off, dst_off, 1, threads)
+        times.append(time.perf_counter() - t0)
+        out_bytes = int(outlen.sum())
+        assert (status == 0).all()
+    sub = max(1, len(comps) // 16)
+    s1, so1, do1 = wl.pack(comps[:sub], sizes[:sub])
+    t1 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, _, ol1 = oracle.infl_batch(s1, so1, do1, 1, 1)
+        t1.append(time.perf_counter() - t0)
+    import zlib
+    t0 = time.perf_counter()
+    zbytes = sum(len(zlib.decompress(c)) for c in comps[:sub])
+    tz = time.perf_counter() - t0
+    med = float(np.median(times))
+    return {
+        "value": round(out_bytes / med / 1e6, 1),
+        "unit": "MB/s",
+        "cores": threads,
+        "kind": "port",
+        "nproc": os.cpu_count(),
+        "cpu_model": cpu_model(),
+        "threads": threads,
+        "passes": len(times),
+        "spread_MB_per_s": [round(out_bytes / max(times) / 1e6, 1), round(out_bytes / min(times) / 1e6, 1)],
+        "one_thread_MB_per_s": round(int(ol1.sum()) / float(np.median(t1)) / 1e6, 1),
+        "system_zlib_one_thread_MB_per_s": round(zbytes / tz / 1e6, 1),
+        "sample": "%d distinct streams of this workload, median of %d passes on %d threads (the cores the job "
+                  "may use; the machine has %d)" % (len(comps), len(times), threads, os.cpu_count() or 0),
+    }
+
+
+def relaunch(args, argv):
+    """--gpus N > 1 without a launcher: start one process per GPU through torch.distributed.run
+    and pass its output on.  Runs before this process has touched a GPU and never touches one."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+class Batch:
+    """This rank's streams: global stream g of the batch is pool stream g % pool; the rank owns the
+    contiguous range [lo, hi).  Device layout: one source arena + u64 offsets, one destination arena +
+    u64 offsets (capacity = the stream's decompressed size), status and length arrays."""
+
+    def __init__(self, torch, dev, comps, sizes, lo, hi):
+        self.torch, self.dev, self.lo, self.hi = torch, dev, lo, hi
+        pool = len(comps)
+        self.pool, self.n = pool, hi - lo
+        clen = np.array([len(c) for c in comps], dtype=np.uint64)
+        ulen = np.array(sizes, dtype=np.uint64)
+        idx = np.arange(lo, hi, dtype=np.int64) % pool
+        self.src_off = np.zeros(self.n + 1, dtype=np.uint64)
+        self.dst_off = np.zeros(self.n + 1, dtype=np.uint64)
+        np.cumsum(clen[idx], out=self.src_off[1:])
+        np.cumsum(ulen[idx], out=self.dst_off[1:])
+        self.comp_bytes, self.out_bytes = int(self.src_off[-1]), int(self.dst_off[-1])
+        # source arena: the pool block tiled on the device, cut to the rank's range
+        blk = torch.from_numpy(np.frombuffer(b"".join(comps), dtype=np.uint8).copy()).to(dev)
+        cs = np.concatenate([[0], np.cumsum(clen)]).astype(np.int64)       # pool prefix sums
+        self.us = np.concatenate([[0], np.cumsum(ulen)]).astype(np.int64)
+        b0, b1 = lo // pool, (hi + pool - 1) // pool                       # blocks touched
+        tiled = blk.repeat(b1 - b0)
+        start = int(cs[lo - b0 * pool])
+        self.d_src = torch.cat([tiled[start:start + self.comp_bytes], torch.zeros(64, dtype=torch.uint8, device=dev)])
+        del tiled, blk
+        self.d_dst = torch.empty(self.out_bytes + 64, dtype=torch.uint8, device=dev)
+        self.d_soff = torch.from_numpy(self.src_off.view(np.int64)).to(dev)
+        self.d_doff = torch.from_numpy(self.dst_off.view(np.int64)).to(dev)
+        self.d_status = torch.full((max(1, self.n),), -99, dtype=torch.int32, device=dev)
+        self.d_outlen = torch.zeros(max(1, self.n), dtype=torch.int32, device=dev)
+        self.want_len = torch.from_numpy(ulen[idx].astype(np.int32)).to(dev)
+
+    def verify(self, oracle, comps, sizes, threads):
+        """Every output of the rank against the CPU oracle: the first occurrence of every distinct
+        stream byte for byte on the host, every further occurrence byte for byte against that first
+        one on the device.  Returns (streams checked against the oracle, streams checked in all)."""
+        torch, pool, lo, hi = self.torch, self.pool, self.lo, self.hi
+        ok = bool((self.d_status[: self.n] == 0).all()) and bool((self.d_outlen[: self.n] == self.want_len).all())
+        if not ok or self.n == 0:
+            return ok, 0, 0
+        blk_out = int(self.us[-1])
+        # reference block: the oracle's output for pool streams 0 .. pool-1, on the device
+        src, so, do = wl.pack(comps, sizes)
+        want, wst, wol = oracle.infl_batch(src, so, do, 1, threads)
+        ok = bool((wst == 0).all()) and bool((wol == np.array(sizes)).all())
+        d_want = torch.from_numpy(want[:blk_out]).to(self.dev)
+        # the rank's output is a run of (partial first block, whole blocks, partial last block)
+        g, at, checked = lo, 0, 0
+        while g < hi and ok:
+            j = g % pool
+            cnt = min(pool - j, hi - g)                                     # streams up to the block's end
+            a, b = int(self.us[j]), int(self.us[j + cnt])
+            ok = torch.equal(self.d_dst[at:at + (b - a)], d_want[a:b])
+            at += b - a
+            g += cnt
+            checked += cnt
+        return ok, min(pool, self.n), checked
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DEFL_BENCH_STREAMS", 65536)),
-                    help="streams per GPU")
-    ap.add_argument("--pool", type=int, default=int(os.environ.get("DEFL_BENCH_POOL", 2048)),
-                    help="distinct streams generated per GPU; the batch tiles them into distinct "
-                         "source and destination slots")
+    ap.add_argument("--workload", default=os.environ.get("DEFL_BENCH_WORKLOAD", "text64k"), choices=sorted(FULL_STREAMS))
+    ap.add_argument("--scaling", default=os.environ.get("DEFL_BENCH_SCALING", "weak"), choices=["weak", "strong"])
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DEFL_BENCH_STREAMS", 0)),
+                    help="streams of the full batch (default: the workload's size); weak scaling gives every "
+                         "GPU such a batch, strong scaling splits one")
+    ap.add_argument("--pool", type=int, default=int(os.environ.get("DEFL_BENCH_POOL", 8192)),
+                    help="distinct streams generated; the batch tiles them into distinct source and "
+                         "destination slots")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("DEFL_BENCH_LANES", 16)))
     ap.add_argument("--variant", type=int, default=int(os.environ.get("DEFL_BENCH_VARIANT", 2)),
                     help="0 = tables in the reference geometry, 1 = compact tables + deferred pass, "
                          "2 = wavefront-parallel block decode + deferred pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(relaunch(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -108,14 +239,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)"
-                         % (args.gpus, world))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # Rehearsal aids for a box with fewer GPUs than ranks (the measured runs use neither): all ranks on
+    # device 0, and gloo (CPU tensors only) instead of RCCL, which refuses two ranks on one device.
+    one_gpu = os.environ.get("DEFL_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("DEFL_BENCH_BACKEND", "nccl")
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     note("torch ready, loading engine")
     eng = capi.load()
@@ -124,34 +263,31 @@ def main():
     eng.lib.infl_gpu_set_lanes_per_stream(args.lanes)
     eng.lib.infl_gpu_set_table_variant(args.variant)
 
-    n, pool = args.streams, min(args.pool, args.streams)
-    workers = 4
-    note("generating %d streams with %d workers" % (pool, workers))
-    comps = build_pool(rank * pool, pool, workers)
-    note("uploading")
+    full = args.streams or FULL_STREAMS[args.workload]
+    pool = max(1, min(args.pool, full))
+    threads = host_threads()
+    workers = max(1, min(threads, 16) // max(1, min(world, 8)))
+    note("generating %d distinct streams with %d threads" % (pool, workers))
+    sizes = pool_sizes(args.workload, pool)
+    # weak scaling: every rank has its own distinct streams; strong scaling: one batch for all
+    comps = build_pool(rank * pool if args.scaling == "weak" else 0, sizes, workers)
 
-    # device layout: one contiguous src arena + u64 offsets, dst arena with 64 KiB stride
-    reps = (n + pool - 1) // pool
-    lens = np.array([len(c) for c in comps], dtype=np.uint64)
-    lens_all = np.tile(lens, reps)[:n]
-    src_off = np.zeros(n + 1, dtype=np.uint64)
-    np.cumsum(lens_all, out=src_off[1:])
-    dst_off = np.arange(n + 1, dtype=np.uint64) * STREAM_BYTES
-    pool_bytes = torch.from_numpy(np.frombuffer(b"".join(comps), dtype=np.uint8).copy()).to(dev)
-    d_src = pool_bytes.repeat(reps)[: int(src_off[-1])].contiguous()
-    d_src = torch.cat([d_src, torch.zeros(64, dtype=torch.uint8, device=dev)])
-    d_dst = torch.empty(n * STREAM_BYTES + 64, dtype=torch.uint8, device=dev)
-    d_soff = torch.from_numpy(src_off.view(np.int64)).to(dev)
-    d_doff = torch.from_numpy(dst_off.view(np.int64)).to(dev)
-    d_status = torch.full((n,), -99, dtype=torch.int32, device=dev)
-    d_outlen = torch.zeros(n, dtype=torch.int32, device=dev)
-    comp_bytes = int(src_off[-1])
-    out_bytes = n * STREAM_BYTES
+    if args.scaling == "weak":
+        lo, hi = 0, full
+        cost_share = None
+    else:
+        clen = np.array([len(c) for c in comps], dtype=np.float64)
+        cost = (clen + np.array(sizes, dtype=np.float64))[np.arange(full) % pool]
+        parts = shard.partition(cost, world)
+        lo, hi = parts[rank]
+        cost_share = [float(cost[a:b].sum()) for a, b in parts]
+    note("uploading streams [%d, %d)" % (lo, hi))
+    b = Batch(torch, dev, comps, sizes, lo, hi)
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
-        rc = eng.lib.infl_batch_dev(d_src.data_ptr(), d_soff.data_ptr(), d_dst.data_ptr(), d_doff.data_ptr(),
-                                    1, n, d_status.data_ptr(), d_outlen.data_ptr(), stream)
+        rc = eng.lib.infl_batch_dev(b.d_src.data_ptr(), b.d_soff.data_ptr(), b.d_dst.data_ptr(), b.d_doff.data_ptr(),
+                                    1, b.n, b.d_status.data_ptr(), b.d_outlen.data_ptr(), stream)
         if rc != 0:
             raise RuntimeError("infl_batch_dev failed")
 
@@ -163,21 +299,6 @@ def main():
     for _ in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
-    note("parity gate")
-
-    # parity gate: every stream complete, and the first `pool` outputs bit-exact vs the oracle
-    from tests import oracle_lib
-    oracle = oracle_lib.load()
-    assert bool((d_status == 0).all()) and bool((d_outlen == STREAM_BYTES).all()), "decode failed"
-    chk = min(pool, 256)
-    s_np, so_np, do_np = wl.pack(comps[:chk], [STREAM_BYTES] * chk)
-    want, wst, wol = oracle.infl_batch(s_np, so_np, do_np, 1, 8)
-    got = d_dst[: chk * STREAM_BYTES].cpu().numpy()
-    assert np.array_equal(got, want[: chk * STREAM_BYTES]), "output differs from the CPU oracle"
-    # all tiles must equal the pool outputs (64-bit sums per stream as a checksum of checksums)
-    sums = d_dst[: n * STREAM_BYTES].view(n, STREAM_BYTES).to(torch.int64).sum(dim=1) if n <= 8192 else None
-    if sums is not None:
-        assert bool((sums.view(-1)[:pool * (n // pool)].view(-1, pool) == sums[:pool]).all())
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -192,33 +313,44 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([x.elapsed_time(y) for x, y in ev]))
 
-    tot = torch.tensor([elapsed, float(bool((d_status == 0).all())), float(out_bytes)],
-                       dtype=torch.float64, device=dev)
+    # parity gate, on what the timed steps left in memory: every stream of the rank against the oracle
+    note("parity gate")
+    from tests import oracle_lib
+    oracle = oracle_lib.load()
+    ok, n_oracle, n_checked = b.verify(oracle, comps, sizes, threads)
+
+    n_ok, n_err, bytes_ok = shard.summarize(b.d_status[: b.n], b.d_outlen[: b.n], dist if world > 1 else None, device=dev)
+    per = torch.tensor([elapsed, float(ok), float(n_checked), float(b.comp_bytes + b.out_bytes), kern_ms],
+                       dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
-        tmax = tot.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        all_ok = float(tot[1]) == world
-        total_out = float(tot[2])
+        allr = [torch.zeros_like(per) for _ in range(world)]
+        dist.all_gather(allr, per)
+        allr = torch.stack(allr).cpu().numpy()
     else:
-        all_ok, total_out = bool(tot[1]), float(out_bytes)
-    assert all_ok
+        allr = per.cpu().numpy()[None, :]
+    elapsed = float(allr[:, 0].max())
+    all_ok = bool((allr[:, 1] == 1.0).all()) and n_err == 0
+    if not all_ok:
+        raise SystemExit("parity gate failed: %d streams in error, per-rank check %s" % (n_err, allr[:, 1].tolist()))
 
     if rank == 0:
-        value = total_out * args.steps / elapsed / 1e6
-        achieved = (comp_bytes + out_bytes) / (kern_ms * 1e-3) / 1e9
+        total_streams = n_ok
+        value = bytes_ok * args.steps / elapsed / 1e6
+        achieved = (b.comp_bytes + b.out_bytes) / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 t = json.load(open(tpath))
-                if t.get("streams") == n and t.get("variant", args.variant) == args.variant:
+                if (t.get("streams") == b.n and t.get("workload", "text64k") == args.workload
+                        and t.get("variant", args.variant) == args.variant):
                     traffic = t.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        names = {"text64k": "64 KiB zlib level-6 streams", "mixed": "zlib level-6 streams of 1 KiB .. 256 KiB (log-uniform)"}
+        load = allr[:, 3]
         res = {
             "metric": "decompressed_MB_per_s",
             "value": round(value, 1),
@@ -228,21 +360,27 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": "batch of %d independent 64 KiB zlib level-6 streams per GPU (dynamic Huffman, "
-                            "synthetic Zipf text), one launch, inputs and outputs resident in HBM" % n,
-                "streams_per_gpu": n,
-                "distinct_streams_per_gpu": pool,
-                "stream_bytes": STREAM_BYTES,
-                "compressed_ratio": round(comp_bytes / out_bytes, 4),
+                "workload": "batch of %d independent %s %s (dynamic Huffman, synthetic Zipf text), one launch per "
+                            "GPU, inputs and outputs resident in HBM"
+                            % (full, names[args.workload], "per GPU" if args.scaling == "weak" else "split over the GPUs"),
+                "streams_total": total_streams,
+                "streams_rank0": b.n,
+                "distinct_streams": pool if args.scaling == "strong" else pool * world,
+                "compressed_ratio": round(b.comp_bytes / max(1, b.out_bytes), 4),
                 "lanes_per_stream": args.lanes,
                 "table_variant": args.variant,
                 "parallelism": "stream-shard x%d, no data-path collective" % world,
-                "bit_exact_vs_oracle": True,
+                "bit_exact_vs_oracle": all_ok,
+                "parity_gate": "after the timed steps: every distinct stream of a rank against the CPU oracle byte for "
+                               "byte (%d on rank 0), every tile of it against that block on the device (%d streams on "
+                               "rank 0, %d over all ranks)" % (n_oracle, n_checked, int(allr[:, 2].sum())),
+                "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in allr[:, 0].tolist()],
+                "per_rank_load_imbalance": round(float(load.max() / load.mean()), 4),
             },
             "roofline": {
                 "bound": "hbm",
@@ -253,13 +391,15 @@ def main():
                 "traffic": traffic,
                 "kernel": "infl_batch_kernel",
                 "kernel_ms": round(kern_ms, 4),
-                "algorithmic_bytes_per_launch": comp_bytes + out_bytes,
+                "algorithmic_bytes_per_launch": b.comp_bytes + b.out_bytes,
             },
         }
+        if cost_share is not None:
+            res["config"]["partition_cost_share"] = [round(c / max(1.0, sum(cost_share)), 4) for c in cost_share]
         if not args.no_cpu_baseline and world == 1:
-            note("cpu baseline")
-            threads = max(1, min(16, os.cpu_count() or 1))
-            res["cpu_baseline"] = cpu_baseline(comps[: min(pool, 1024)], oracle, threads, 12.0)
+            note("cpu baseline on %d threads" % threads)
+            k = min(pool, 1024)
+            res["cpu_baseline"] = cpu_baseline(comps[:k], sizes[:k], oracle, threads, 12.0)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -16,7 +16,7 @@
 //   RefFmt      32-bit entries in the reference's own geometry (10-bit literal
 //               and 8-bit distance main tables, 2048 / 512 entries).  Decodes
 //               every stream and produces the reference's exact failure result.
-//   CompactFmt  16-bit entries, 9-bit / 7-bit main tables, 768 / 320 entries:
+//   CompactFmt  16-bit entries, 9-bit / 7-bit main tables, 856 / 404 entries:
 //               a quarter of the LDS per stream, so four times as many streams
 //               are in flight per CU.  A stream whose tables do not fit, or
 //               that fails in any way, is handed over ("deferred") to a second
@@ -112,7 +112,12 @@ struct RefFmt {
 struct CompactFmt {
   typedef uint16_t entry_t;
   static constexpr int LIT_BITS = 9, DIST_BITS = 7;
-  static constexpr int LIT_CAP = 768, DIST_CAP = 320;
+  // Capacities that take every COMPLETE code: with a 9-bit main table 288 literal/length symbols of
+  // up to 15 bits need at most 854 entries, with a 7-bit one 32 distance symbols at most 402 (the
+  // search zlib's enough.c makes, which gives its 852 / 592 for 286 symbols at 9 bits and 30 at 6).
+  // Smaller tables (768 / 320) sent 3 of 8 192 level-6 text streams, whose 15-bit distance codes
+  // need 386 entries, to the serial passes, where one stream takes as long as a whole batch.
+  static constexpr int LIT_CAP = 856, DIST_CAP = 404;
   static constexpr uint32_t F_LITERAL = 1u << 15, F_BASE = 1u << 14, F_SUB = 1u << 13, F_END = 1u << 12;
   static constexpr uint32_t F_L258 = 1u << 11;
 

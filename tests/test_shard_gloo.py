@@ -51,6 +51,55 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
+def _bench_worker(rank, world, port, q):
+    """The data path of bench.py --scaling strong on CPU tensors: the same partition, the same Batch
+    layout and parity gate, the same counter reduction; the decode itself is done by the oracle."""
+    import torch
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import oracle_lib
+    oracle = oracle_lib.load()
+    pool, full = 24, 100                                   # 4 tiles of the pool and a partial fifth
+    sizes = bench.pool_sizes("mixed", pool)
+    sizes = [min(s, 20000) for s in sizes]
+    comps = bench.build_pool(0, sizes, 1)
+    cost = (np.array([len(c) for c in comps], dtype=np.float64) + np.array(sizes))[np.arange(full) % pool]
+    lo, hi = shard.partition(cost, world)[rank]
+    b = bench.Batch(torch, torch.device("cpu"), comps, sizes, lo, hi)
+    dst, status, outlen = oracle.infl_batch(b.d_src.numpy(), b.src_off, b.dst_off, 1, 1)
+    b.d_dst[: b.out_bytes] = torch.from_numpy(dst[: b.out_bytes])
+    b.d_status[: b.n] = torch.from_numpy(status)
+    b.d_outlen[: b.n] = torch.from_numpy(outlen.astype(np.int32))
+    ok, n_oracle, n_checked = b.verify(oracle, comps, sizes, 1)
+    # a wrong byte in the last stream of the rank must be seen
+    b.d_dst[b.out_bytes - 1] ^= 1
+    ok_bad, _, _ = b.verify(oracle, comps, sizes, 1)
+    b.d_dst[b.out_bytes - 1] ^= 1
+    tot = shard.summarize(b.d_status[: b.n], b.d_outlen[: b.n], dist)
+    q.put((rank, lo, hi, ok, ok_bad, n_checked, tot, int(cost.sum()) - sum(len(comps[g % pool]) for g in range(full))))
+    dist.destroy_process_group()
+
+
+def test_world2_bench_strong_scaling_path():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == 100      # the ranges cover the batch
+    for rank, lo, hi, ok, ok_bad, n_checked, (n_ok, n_err, nbytes), want_bytes in got:
+        assert ok and not ok_bad and n_checked == hi - lo
+        assert (n_ok, n_err, nbytes) == (100, 0, want_bytes)
+
+
 def test_world2_shard_and_reduce():
     n, world = 40, 2
     ctx = mp.get_context("spawn")
