@@ -35,6 +35,24 @@ extern "C" {
 #define INFL_F_ZLIB      0x001
 #define INFL_F_PROGRESS  0x100
 
+/* What infl_stream() keeps between calls (device side): the bit position of the symbol to go on
+   with, the bit position of the header of the block it belongs to, the output position. */
+#define INFL_RS_HEADER   1u    /* the zlib wrapper (if any) has been read            */
+#define INFL_RS_INBLOCK  2u    /* `bit` lies inside a Huffman block, behind its header */
+#define INFL_RS_DONE     4u    /* the final block is complete                          */
+typedef struct InflResume {
+  uint64_t bit, block_bit;
+  uint32_t pos, flags;
+  int32_t  detail;              /* INFL_D_* of the last call */
+  uint32_t reserved;
+} InflResume;
+
+/* Enqueues the one-stream incremental decode: src[0 .. srclen) is all the input seen so far,
+   dst[0 .. cap) the output so far and the room behind it, *state (device memory) where the last
+   call stopped and where this one does.  0 or -1. */
+int infl_launch_resume(const void *src, uint32_t srclen, void *dst, uint32_t cap, int zlib,
+                       InflResume *state, void *stream);
+
 /* Enqueues the batch kernel; all pointers are device pointers; `detail` (why a
    stream stopped) and `inpos` (input bytes consumed) may be NULL.  lanes =
    lanes of a wavefront per stream (64/32/16/8).  variant 0 = one launch with
@@ -65,6 +83,14 @@ void  infl_rt_pinned_release(void *p);
 int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
                        const uint64_t *dst_off, void * const *dst_ptrs, int flags, size_t n,
                        int32_t *status, uint32_t *outlen, int32_t *detail, uint32_t *inpos);
+
+/* One step of infl_stream(): *ctxp is the stream's device context (NULL before the first call,
+   set by the call, released with infl_rt_stream_free); acc[0 .. acc_len) is all the input fed so
+   far, dst/dstlen the caller's output buffer, dstpos the output position before the call.  The new
+   output bytes are copied to dst and *out says where the decode stands.  0, -12 or -1. */
+int  infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst, uint32_t dstlen,
+                         uint32_t dstpos, int zlib, InflResume *out);
+void infl_rt_stream_free(void *ctx);
 
 #ifdef __cplusplus
 }

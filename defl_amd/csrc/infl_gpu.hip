@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <new>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -429,6 +430,84 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
   }
   for (auto &th : pool) th.join();
   return ok && cuts[nsl] == n ? 0 : -1;
+}
+
+// ---- infl_stream(): one device context per stream object ------------------------------------
+// The input seen so far and the output produced so far stay on the device between calls, so a
+// call uploads only the new input bytes and downloads only the new output bytes.
+struct StreamCtx {
+  void       *d_src = nullptr, *d_dst = nullptr;
+  size_t      src_cap = 0, src_up = 0, dst_cap = 0;
+  InflResume *d_state = nullptr;
+};
+
+void infl_rt_stream_free(void *ctx) {
+  StreamCtx *c = (StreamCtx *)ctx;
+  if (!c) return;
+  if (c->d_src) (void)hipFree(c->d_src);
+  if (c->d_dst) (void)hipFree(c->d_dst);
+  if (c->d_state) (void)hipFree(c->d_state);
+  delete c;
+}
+
+int infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst, uint32_t dstlen,
+                        uint32_t dstpos, int zlib, InflResume *out) {
+  if (!ctxp || !out || acc_len > 0xffffffffu) return -1;
+  if (!device_ready()) return -1;
+  StreamCtx *c = (StreamCtx *)*ctxp;
+  if (!c) {
+    c = new (std::nothrow) StreamCtx();
+    if (!c) return -12;
+    if (hipMalloc((void **)&c->d_state, sizeof(InflResume)) != hipSuccess ||
+        hipMemset(c->d_state, 0, sizeof(InflResume)) != hipSuccess) {
+      (void)hipGetLastError();
+      infl_rt_stream_free(c);
+      return -12;
+    }
+    *ctxp = c;
+  }
+  if (acc_len + 16 > c->src_cap) {                    // grow the input arena: everything goes up again
+    const size_t want = std::max(acc_len + 16 + acc_len / 2, (size_t)4096);
+    void *n = nullptr;
+    if (hipMalloc(&n, want) != hipSuccess) {
+      (void)hipGetLastError();
+      return -12;
+    }
+    if (c->d_src) (void)hipFree(c->d_src);
+    c->d_src   = n;
+    c->src_cap = want;
+    c->src_up  = 0;
+  }
+  if ((size_t)dstlen + 16 > c->dst_cap) {             // a larger output buffer (infl_resize_output): keep what is there
+    const size_t want = (size_t)dstlen + 16;
+    void *n = nullptr;
+    if (hipMalloc(&n, want) != hipSuccess) {
+      (void)hipGetLastError();
+      return -12;
+    }
+    bool ok = true;
+    if (c->d_dst && dstpos) ok = hipMemcpy(n, c->d_dst, std::min((size_t)dstpos, c->dst_cap), hipMemcpyDeviceToDevice) == hipSuccess;
+    if (c->d_dst) (void)hipFree(c->d_dst);
+    c->d_dst   = n;
+    c->dst_cap = want;
+    if (!ok) return -1;
+  }
+  bool ok = true;
+  if (acc_len > c->src_up) {
+    ok &= hipMemcpy((uint8_t *)c->d_src + c->src_up, (const uint8_t *)acc + c->src_up, acc_len - c->src_up,
+                    hipMemcpyHostToDevice) == hipSuccess;
+    c->src_up = acc_len;
+  }
+  ok = ok && infl_launch_resume(c->d_src, (uint32_t)acc_len, c->d_dst, dstlen, zlib ? 1 : 0, c->d_state, nullptr) == 0;
+  ok = ok && hipMemcpy(out, c->d_state, sizeof(InflResume), hipMemcpyDeviceToHost) == hipSuccess;
+  if (ok && out->pos > dstpos && out->pos <= dstlen)
+    ok = hipMemcpy((uint8_t *)dst + dstpos, (const uint8_t *)c->d_dst + dstpos, out->pos - dstpos,
+                   hipMemcpyDeviceToHost) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return 0;
 }
 
 int infl_batch_noalloc(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,

@@ -65,6 +65,9 @@ struct unz__stream_t {
   size_t    gather_cap;
 
   int       stream_done;          /* infl_stream() reached the final block */
+  uint8_t  *acc;                  /* infl_stream(): every input byte fed so far, contiguous */
+  size_t    acc_len, acc_cap;
+  void     *sctx;                 /* its device context (input, output and decode position stay on the device) */
 };
 
 static void
@@ -96,6 +99,11 @@ infl_reset_pool(infl_stream_t * __restrict st) {
   st->pages_used = 0;
   st->page_fill  = 0;
   st->appending  = 0;
+  st->acc_len    = 0;
+  if (st->sctx) {                                 /* the incremental decode starts over with the input */
+    infl_rt_stream_free(st->sctx);
+    st->sctx = NULL;
+  }
 }
 
 UNZ_EXPORT void
@@ -139,6 +147,9 @@ infl_destroy(infl_stream_t * __restrict st) {
   free(st->pages);
   free(st->pieces);
   free(st->gather);
+  free(st->acc);
+  if (st->sctx)
+    infl_rt_stream_free(st->sctx);
   free(st);
 }
 
@@ -284,26 +295,67 @@ infl(infl_stream_t * __restrict st) {
   return decode_one(st, st->flags == INFL_ZLIB ? INFL_ZLIB : 0, &detail);
 }
 
+static int
+acc_append(infl_stream_t *st, const void *p, size_t len) {
+  if (st->acc_len + len > st->acc_cap) {
+    size_t   cap = st->acc_cap ? st->acc_cap * 2 : 4096;
+    uint8_t *nb;
+    while (cap < st->acc_len + len)
+      cap *= 2;
+    nb = (uint8_t *)realloc(st->acc, cap);
+    if (!nb)
+      return -1;
+    st->acc     = nb;
+    st->acc_cap = cap;
+  }
+  if (len)
+    memcpy(st->acc + st->acc_len, p, len);
+  st->acc_len += len;
+  return 0;
+}
+
+/* Incremental decode (reference src/infl/stream.c:468-794): every call adds its bytes to the input
+   and decodes on from where the last call stopped (a block header or a symbol boundary; the GPU
+   keeps input, output and position, see infl_resume_kernel).  UNZ_UNFINISHED while the stream wants
+   more input, UNZ_EFULL when the output buffer is full (go on after infl_resize_output), UNZ_OK once
+   the final block is complete. */
 UNZ_EXPORT int
 infl_stream(infl_stream_t * __restrict st, const void * __restrict src, uint32_t srclen) {
-  int32_t detail = INFL_D_OK;
-  int     rc;
+  InflResume rs;
+  int        rc;
 
   if (!st)
     return UNZ_ERR;
-  if (src && srclen > 0)
-    infl_include(st, src, srclen);
-  else if (st->npieces == 0)
+  if (st->acc_len == 0 && st->npieces) {          /* input given with infl_include() before: it comes first */
+    for (size_t i = 0; i < st->npieces; i++)
+      if (acc_append(st, st->pieces[i].p, st->pieces[i].len) != 0)
+        return UNZ_ENOMEM;
+  }
+  if (src && srclen > 0) {
+    if (acc_append(st, src, srclen) != 0)
+      return UNZ_ENOMEM;
+  } else if (st->acc_len == 0) {
     return UNZ_OK;                                /* "empty data", stream.c:489-493 */
+  }
   if (st->stream_done)
     return UNZ_OK;
+  if (st->acc_len > UINT32_MAX)
+    return UNZ_ERR;
 
-  rc = decode_one(st, (st->flags == INFL_ZLIB ? INFL_ZLIB : 0) | INFL_F_PROGRESS, &detail);
-  if (rc == UNZ_OK) {
+  rc = infl_rt_stream_step(&st->sctx, st->acc, st->acc_len, st->dst, st->dstlen, st->dstpos,
+                           st->flags == INFL_ZLIB, &rs);
+  if (rc != 0) {
+    if (rc == -1)
+      warn_no_device();
+    return rc == -12 ? UNZ_ENOMEM : UNZ_ERR;
+  }
+  st->dstpos = rs.pos;
+  st->inpos  = (uint32_t)((rs.bit + 7u) >> 3);
+  if (rs.flags & INFL_RS_DONE) {
     st->stream_done = 1;
     return UNZ_OK;
   }
-  switch (detail) {
+  switch (rs.detail) {
     case INFL_D_NEED_INPUT: return UNZ_UNFINISHED;
     case INFL_D_FULL:       return UNZ_EFULL;
     default:                return UNZ_ERR;

@@ -262,6 +262,10 @@ __device__ __forceinline__ void rd_drop(Reader &r, uint32_t k) {
 
 // first input byte that still has unread bits
 __device__ __forceinline__ const uint8_t *rd_byte_ptr(const Reader &r) { return r.p - (r.n >> 3); }
+// bits consumed since `origin`
+__device__ __forceinline__ uint64_t rd_bitpos(const Reader &r, const uint8_t *origin) {
+  return (uint64_t)(r.p - origin) * 8u - r.n;
+}
 
 // Reader of the compact-table pass.  The group keeps a window of 4 * T input
 // bytes in registers (lane j holds word j) plus the next window, prefetched one
@@ -343,6 +347,10 @@ __device__ __forceinline__ const uint8_t *rd_byte_ptr(const FastReader<T> &r) {
 }
 template <int T>
 __device__ __forceinline__ const uint8_t *rd_end(const FastReader<T> &r) { return r.src + r.ilen; }
+template <int T>
+__device__ __forceinline__ uint64_t rd_bitpos(const FastReader<T> &r, const uint8_t *origin) {
+  return (uint64_t)(r.src - origin) * 8u + (uint64_t)r.ipos * 8u - r.n;
+}
 // true once bits past the end of the stream have been consumed (see the reader's comment)
 template <int T>
 __device__ __forceinline__ bool rd_overrun(const FastReader<T> &r) {
@@ -713,14 +721,18 @@ __device__ __forceinline__ int stored_block(R &r, uint8_t *dst, uint32_t &pos, u
 }
 
 // One Huffman-coded block (rules of infl.c:717-901).
+// With `symbit` the bit offset (from `origin`) of the symbol the loop stopped at is stored there:
+// the first symbol that was not carried out, behind which a later call can go on (infl_stream).
 template <int T, class F, class R>
 __device__ __forceinline__ int huffman_block(R &r, uint8_t *dst, uint32_t &pos_io, uint32_t cap,
-                                             const StreamLds<F> &L, int lig, uint64_t &fuel) {
+                                             const StreamLds<F> &L, int lig, uint64_t &fuel,
+                                             uint64_t *symbit = nullptr, const uint8_t *origin = nullptr) {
   (void)fuel;   // every turn consumes >= 1 bit of a finite input; blocks are counted by the caller
   uint32_t pos = pos_io;
   int      rc  = INFL_D_OK;
   for (;;) {
     rd_fill(r);
+    if (symbit) *symbit = rd_bitpos(r, origin);
     Sym s = F::lit_sym(tab_lookup<F>(L.lit, F::LIT_BITS, (uint32_t)r.bits));
     if (s.kind == K_INVALID) { rc = INFL_D_INVALID; break; }
     uint32_t total = s.codelen + s.xbits;
@@ -1747,6 +1759,103 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------
+// Incremental decode of ONE stream (infl_stream(), reference src/infl/stream.c:468-794): the
+// input seen so far is decoded from where the last call stopped, symbol by symbol, by one
+// wavefront with tables in the reference's geometry.  The state kept between calls is small:
+// the bit position of the symbol to go on with, the output position, and the bit position of
+// the header of the block that symbol belongs to (the tables are built again from it; the
+// reference keeps its tables in the stream object instead, stream.c:348-352, 669-675).
+// A stop is always at a block header or at a symbol boundary: a symbol that lacks input bits
+// or output space is left for the next call as a whole.
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(64, 1) void infl_resume_kernel(const uint8_t *__restrict__ src, uint32_t srclen,
+                                                             uint8_t *__restrict__ dst, uint32_t cap, int zlib,
+                                                             InflResume *__restrict__ state) {
+  typedef RefFmt F;
+  static_assert(T == 64, "one wavefront decodes the stream");
+  __shared__ StreamLds<F> L;
+  const int lig = threadIdx.x;
+  uint64_t  bit = state->bit, block_bit = state->block_bit;
+  uint32_t  pos = state->pos, flags = state->flags;
+  group_sync();                                      // every lane has read the state before lane 0 writes it
+  int       rc = INFL_D_OK;
+  uint64_t  fuel = (uint64_t)srclen * 8u + 64u;
+  Reader    r;
+  r.end = src + srclen;
+  auto seek = [&](uint64_t at) {
+    rd_seek(r, src + (at >> 3));
+    rd_fill(r);
+    rd_drop(r, (uint32_t)(at & 7u));
+  };
+  if (!(flags & INFL_RS_HEADER)) {                   // zlib wrapper (infl.c:1027-1039), empty for raw streams
+    if (zlib) {
+      if (srclen < 2) rc = INFL_D_NEED_INPUT;
+      else if (!zlib_header_ok(src)) rc = INFL_D_INVALID;
+      else bit = block_bit = 16;
+    }
+    if (rc == INFL_D_OK) flags |= INFL_RS_HEADER;
+  }
+  while (rc == INFL_D_OK && !(flags & INFL_RS_DONE)) {
+    if (fuel-- == 0) {
+      rc = INFL_D_INTERNAL;
+      break;
+    }
+    // the block header (again, when the call resumes inside the block: it gives the tables)
+    seek(block_bit);
+    if (rd_real(r) < 3) {
+      rc = INFL_D_NEED_INPUT;
+      break;
+    }
+    const uint32_t bfinal = (uint32_t)r.bits & 1u, btype = ((uint32_t)r.bits >> 1) & 3u;
+    rd_drop(r, 3);
+    if (btype == 3) {
+      rc = INFL_D_INVALID;
+      break;
+    }
+    if (btype == 0) {                                // stored: carried out once it is there as a whole
+      rc = stored_block<T>(r, dst, pos, cap, lig);
+      if (rc != INFL_D_OK) break;
+      bit = block_bit = rd_bitpos(r, src);
+      flags &= ~INFL_RS_INBLOCK;
+      if (bfinal) flags |= INFL_RS_DONE;
+      continue;
+    }
+    int b;
+    if (btype == 1) {
+      const int f = setup_fixed<T, F>(L, lig, 0);
+      b = f == BUILD_OK ? INFL_D_OK : INFL_D_INTERNAL;
+    } else {
+      b = setup_dynamic<T, F>(r, L, lig, 0);
+    }
+    if (b != INFL_D_OK) {
+      rc = b == INFL_D_NOFIT ? INFL_D_INTERNAL : b;
+      break;
+    }
+    if (flags & INFL_RS_INBLOCK) seek(bit);          // go on at the symbol the last call stopped at
+    flags |= INFL_RS_INBLOCK;
+    uint64_t symbit = rd_bitpos(r, src);
+    rc = huffman_block<T, F>(r, dst, pos, cap, L, lig, fuel, &symbit, src);
+    if (rc != INFL_D_OK) {
+      bit = symbit;                                  // (block_bit stays)
+      break;
+    }
+    bit = block_bit = rd_bitpos(r, src);
+    flags &= ~INFL_RS_INBLOCK;
+    if (bfinal) flags |= INFL_RS_DONE;
+  }
+  if (rc != INFL_D_OK && !(flags & INFL_RS_INBLOCK)) bit = block_bit;
+  group_sync();
+  if (lig == 0) {
+    state->bit       = bit;
+    state->block_bit = block_bit;
+    state->pos       = pos;
+    state->flags     = flags;
+    state->detail    = rc;
+  }
+}
+
 }  // namespace defl
 
 // variant 0: reference-geometry tables only (one launch).
@@ -1790,6 +1899,13 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
   }
 #undef LAUNCH_T
 #undef LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int infl_launch_resume(const void *src, uint32_t srclen, void *dst, uint32_t cap, int zlib,
+                                  InflResume *state, void *stream) {
+  hipLaunchKernelGGL((defl::infl_resume_kernel<64>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)src,
+                     srclen, (uint8_t *)dst, cap, zlib, state);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

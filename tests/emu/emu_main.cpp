@@ -70,6 +70,10 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
 
 #include "../../defl_amd/csrc/infl_kernels.hip"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
                               int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
                               uint32_t *inpos, int lanes, int variant, void *mirror) {
@@ -89,8 +93,55 @@ extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *ds
 #include <stdlib.h>
 #include <string.h>
 
+// emu_run <in.bin> <out.bin> resume <flags> <chunk>: every stream is fed to the incremental kernel
+// in pieces of <chunk> bytes (the state lives in host memory here); out: i32 status[n] (0 = final
+// block complete, else the detail code of the last call), u32 outlen[n], dst bytes.
+static int main_resume(int argc, char **argv) {
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, f) != 1) return 2;
+  std::vector<uint64_t> so(n + 1), dof(n + 1);
+  if (fread(so.data(), 8, n + 1, f) != n + 1 || fread(dof.data(), 8, n + 1, f) != n + 1) return 2;
+  std::vector<uint8_t> src(so[n] ? so[n] : 1), dst(dof[n] ? dof[n] : 1, 0);
+  if (so[n] && fread(src.data(), 1, so[n], f) != so[n]) return 2;
+  fclose(f);
+  const int flags = atoi(argv[4]);
+  const uint64_t chunk = (uint64_t)atoi(argv[5]);
+  std::vector<int32_t>  status(n, -99);
+  std::vector<uint32_t> outlen(n, 0);
+  emu::g_lanes_per_group = 64;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint64_t len = so[i + 1] - so[i], cap = dof[i + 1] - dof[i];
+    // exact-size copies so that AddressSanitizer sees any access past what has been fed so far
+    InflResume st;
+    memset(&st, 0, sizeof(st));
+    uint8_t *out = (uint8_t *)calloc(1, cap ? cap : 1);
+    uint64_t fed = 0;
+    do {
+      fed = fed + chunk < len ? fed + chunk : len;
+      uint8_t *in = (uint8_t *)malloc(fed ? fed : 1);
+      memcpy(in, src.data() + so[i], fed);
+      if (infl_launch_resume(in, (uint32_t)fed, out, (uint32_t)cap, flags & 1, &st, nullptr) != 0) return 3;
+      free(in);
+      if ((st.flags & INFL_RS_DONE) || (st.detail != INFL_D_NEED_INPUT && st.detail != INFL_D_OK)) break;
+    } while (fed < len);
+    status[i] = (st.flags & INFL_RS_DONE) ? 0 : st.detail;
+    outlen[i] = st.pos;
+    memcpy(dst.data() + dof[i], out, st.pos < cap ? st.pos : cap);
+    free(out);
+  }
+  f = fopen(argv[2], "wb");
+  fwrite(status.data(), 4, n, f);
+  fwrite(outlen.data(), 4, n, f);
+  fwrite(dst.data(), 1, dof[n], f);
+  fclose(f);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 6) return 2;
+  if (!strcmp(argv[3], "resume")) return main_resume(argc, argv);
   FILE *f = fopen(argv[1], "rb");
   if (!f) return 2;
   uint64_t n = 0;

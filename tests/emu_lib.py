@@ -37,3 +37,27 @@ def run(src, src_off, dst_off, flags=0, lanes=64, variant=0, timeout=600, plain=
     inpos = np.frombuffer(raw, dtype=np.uint32, count=n, offset=12 * n)
     dst = np.frombuffer(raw, dtype=np.uint8, offset=16 * n)
     return dst, status, outlen, detail, inpos
+
+
+def run_resume(src, src_off, dst_off, flags=0, chunk=1, timeout=900):
+    """Every stream fed to the incremental (infl_stream) kernel in pieces of `chunk` bytes.
+    -> (dst, status, outlen): status 0 = final block complete, else the last call's detail code."""
+    build()
+    n = len(src_off) - 1
+    src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
+    dst_off = np.ascontiguousarray(dst_off, dtype=np.uint64)
+    src = np.ascontiguousarray(src, dtype=np.uint8)[: int(src_off[-1])]
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.uint64(n).tobytes() + src_off.tobytes() + dst_off.tobytes() + src.tobytes())
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+        p = subprocess.run([EXE, fin, fout, "resume", str(flags), str(chunk), "0"], env=env, timeout=timeout,
+                           capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("emu_run resume failed (%d): %s" % (p.returncode, p.stderr[-3000:]))
+        raw = open(fout, "rb").read()
+    status = np.frombuffer(raw, dtype=np.int32, count=n, offset=0)
+    outlen = np.frombuffer(raw, dtype=np.uint32, count=n, offset=4 * n)
+    dst = np.frombuffer(raw, dtype=np.uint8, offset=8 * n)
+    return dst, status, outlen

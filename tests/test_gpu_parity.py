@@ -344,3 +344,113 @@ def test_streaming_api(engine):
     assert lib.infl_stream(st, None, 0) == capi.UNZ_OK
     assert bytes(big) == raw
     lib.infl_destroy(st)
+
+
+def test_streaming_bytewise_png_simulation(engine):
+    """The reference's byte-wise streaming test (test/test_files.c:792-869, :1120-1129): png_simulation
+    (30 628 compressed bytes) fed to infl_stream() one byte per call, then empty calls until it is done.
+    Every call decodes on from where the last one stopped; bound: a minute for the 30 628 calls."""
+    import ctypes as C
+    import time
+    lib = engine.lib
+    raw, comp = _read("raw", "png_simulation"), _read("compressed", "png_simulation")
+    out = (C.c_uint8 * (len(raw) + 1000))()
+    st = lib.infl_init(out, len(raw) + 1000, 0)
+    src = (C.c_uint8 * len(comp)).from_buffer_copy(comp)
+    t0 = time.time()
+    rc, pos, last_out = capi.UNZ_UNFINISHED, 0, 0
+    while pos < len(comp) and rc == capi.UNZ_UNFINISHED:
+        rc = lib.infl_stream(st, C.byref(src, pos), 1)
+        pos += 1
+        now = lib.infl_output_pos(st)
+        assert now >= last_out                       # the output only ever grows
+        last_out = now
+    tries = 0
+    while rc == capi.UNZ_UNFINISHED and tries < 32:
+        rc = lib.infl_stream(st, None, 0)
+        tries += 1
+    took = time.time() - t0
+    assert rc == capi.UNZ_OK and pos == len(comp)
+    assert bytes(out[:len(raw)]) == raw and lib.infl_output_pos(st) == len(raw)
+    assert took < 60.0, took
+    lib.infl_destroy(st)
+
+
+def test_streaming_edge_vectors(engine):
+    """The three streaming edge inputs of the reference's test program (test/test_files.c:871-1029)."""
+    import ctypes as C
+    import json
+    lib = engine.lib
+    codes = {"ok": capi.UNZ_OK, "unfinished": capi.UNZ_UNFINISHED}
+    with open(os.path.join(HERE, "golden", "kats.json")) as f:
+        vectors = json.load(f)["streaming"]
+    assert len(vectors) == 3
+    for v in vectors:
+        data = bytes.fromhex(v["src"])
+        out = (C.c_uint8 * v["dstlen"])()
+        st = lib.infl_init(out, v["dstlen"], v["flags"])
+        src = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        rc, fed = capi.UNZ_UNFINISHED, 0
+        while fed < len(data) and rc == capi.UNZ_UNFINISHED:
+            n = min(v["feed"], len(data) - fed)
+            rc = lib.infl_stream(st, C.byref(src, fed), n)
+            fed += n
+        assert rc in [codes[c] for c in v["expect_rc"]], (v["name"], rc)
+        want = bytes.fromhex(v["out_prefix"])
+        assert bytes(out[:len(want)]) == want, v["name"]
+        lib.infl_destroy(st)
+
+
+def test_streaming_resumes_inside_blocks(engine, oracle):
+    """infl_stream() against the one-shot decode on streams of several kinds, fed in pieces of 1 to 4096
+    bytes: same bytes, UNZ_OK exactly when the final block is complete, UNZ_UNFINISHED before; a
+    truncated stream stays UNZ_UNFINISHED, a corrupted one turns UNZ_ERR; infl_reset() starts over."""
+    import ctypes as C
+    lib = engine.lib
+    rng = random.Random(91)
+    text = wl.text_stream(31, 50000)
+    c = zlib.compressobj(6)
+    flushed = b"".join(c.compress(text[i:i + 3000]) + c.flush(zlib.Z_SYNC_FLUSH) for i in range(0, 30000, 3000)) + c.flush()
+    cases = [(wl.deflate(text), text, 1), (wl.deflate(text, 6, False, zlib.Z_FIXED), text, 0), (flushed, text[:30000], 1),
+             (wl.stored_stream(3, 70000)[1], wl.stored_stream(3, 70000)[0], 1),
+             (wl.deflate(bytes(40000) + text[:5000], 9), bytes(40000) + text[:5000], 1)]
+    st = None
+    for comp, raw, flags in cases:
+        for step in (1 if len(comp) < 3000 else 7, 333, 4096):
+            out = (C.c_uint8 * len(raw))()
+            if st is None:
+                st = lib.infl_init(out, len(raw), flags)
+            else:
+                lib.infl_reset(st, out, len(raw), flags)
+            src = (C.c_uint8 * len(comp)).from_buffer_copy(comp)
+            rc, fed = capi.UNZ_UNFINISHED, 0
+            while fed < len(comp) and rc == capi.UNZ_UNFINISHED:
+                n = min(step, len(comp) - fed)
+                rc = lib.infl_stream(st, C.byref(src, fed), n)
+                fed += n
+            # done exactly when the final block is in: the zlib trailer (4 bytes) is never read
+            assert rc == capi.UNZ_OK and fed + step > len(comp) - (4 if flags else 0), (len(comp), step, fed, rc)
+            assert lib.infl_output_pos(st) == len(raw)
+            assert bytes(out) == raw
+    # truncated: never more than UNZ_UNFINISHED; corrupted: UNZ_ERR
+    comp = wl.deflate(text)
+    out = (C.c_uint8 * len(text))()
+    lib.infl_reset(st, out, len(text), 1)
+    src = (C.c_uint8 * len(comp)).from_buffer_copy(comp)
+    assert lib.infl_stream(st, src, len(comp) - 9) == capi.UNZ_UNFINISHED
+    assert lib.infl_stream(st, None, 0) == capi.UNZ_UNFINISHED
+    got = lib.infl_output_pos(st)
+    assert 0 < got < len(text) and bytes(out[:got]) == text[:got]
+    assert lib.infl_stream(st, C.byref(src, len(comp) - 9), 9) == capi.UNZ_OK and bytes(out) == text
+    bad = bytearray(comp)
+    bad[len(bad) // 2] ^= 0x55
+    want_rc, _, _, _ = oracle.infl(bytes(bad), len(text), 1)
+    lib.infl_reset(st, out, len(text), 1)
+    srcb = (C.c_uint8 * len(bad)).from_buffer_copy(bytes(bad))
+    rc = capi.UNZ_UNFINISHED
+    for fed in range(0, len(bad), 1000):
+        rc = lib.infl_stream(st, C.byref(srcb, fed), min(1000, len(bad) - fed))
+        if rc != capi.UNZ_UNFINISHED:
+            break
+    assert (rc == capi.UNZ_OK) == (want_rc == 0)
+    lib.infl_destroy(st)

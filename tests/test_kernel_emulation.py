@@ -183,3 +183,36 @@ def test_emulated_parallel_decoder_many_short_blocks(oracle):
         streams += [comp, comp[: len(comp) // 2], comp]
         caps += [len(text), len(text), 3000]
     _compare(oracle, streams, caps, 1, 64, 2)
+
+
+def test_emulated_incremental_kernel(oracle):
+    """The one-stream resume kernel behind infl_stream(): streams fed in pieces of 1 and 61 bytes
+    end where the one-shot decode ends (same bytes, same verdict), whatever the piece size; stops
+    inside dynamic headers, inside matches, at stored blocks and at the output's end included."""
+    rng = random.Random(83)
+    text = wl.text_stream(21, 360)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    multi = c.compress(text[:150]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(text[150:]) + c.flush()
+    streams = [wl.deflate(text, 6, False), wl.deflate(text, 6, False, zlib.Z_FIXED), multi,
+               wl.deflate(bytes(rng.randrange(256) for _ in range(150)), 0, False),
+               bytes.fromhex("000300fcff6162634b494d0300"),            # stored "abc", then fixed "def"
+               wl.deflate(b"a" * 600 + text[:100], 6, False), b"", wl.deflate(text, 6, False)[:-3]]
+    caps = [len(text), len(text), len(text), 150, 10, 700, 10, len(text)]
+    src, src_off, dst_off = wl.pack(streams, caps)
+    want_dst, want_status, want_outlen = oracle.infl_batch(src, src_off, dst_off, 0)
+    for chunk in (1, 61):
+        dst, status, outlen = emu_lib.run_resume(src, src_off, dst_off, 0, chunk)
+        for i in range(len(streams)):
+            if want_status[i] == 0 and len(streams[i]):
+                assert status[i] == 0 and outlen[i] == want_outlen[i], (chunk, i, int(status[i]), int(outlen[i]))
+                a = int(dst_off[i])
+                assert np.array_equal(dst[a:a + int(outlen[i])], want_dst[a:a + int(outlen[i])]), (chunk, i)
+            elif len(streams[i]):
+                assert status[i] == 2, (chunk, i, int(status[i]))       # truncated: still waiting for input
+    # zlib wrapper fed byte by byte, and an output buffer that is too small
+    z = wl.deflate(text)
+    src, src_off, dst_off = wl.pack([z, z, bytes.fromhex("78000300")], [len(text), 100, 10])
+    dst, status, outlen = emu_lib.run_resume(src, src_off, dst_off, 1, 1)
+    assert status[0] == 0 and dst[:len(text)].tobytes() == text
+    assert status[1] == 3 and 0 < outlen[1] <= 100 and dst[len(text):len(text) + int(outlen[1])].tobytes() == text[:int(outlen[1])]
+    assert status[2] == 1
