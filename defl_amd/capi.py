@@ -14,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 
 UNZ_UNFINISHED, UNZ_NOOP, UNZ_OK, UNZ_ERR, UNZ_EFULL = 2, 1, 0, -1, -105
 INFL_ZLIB = 1
-D_OK, D_INVALID, D_NEED_INPUT, D_FULL, D_INTERNAL = 0, 1, 2, 3, 4
+D_OK, D_INVALID, D_NEED_INPUT, D_FULL, D_INTERNAL, D_CHECKSUM = 0, 1, 2, 3, 4, 5
+CHECK_ADLER32, CHECK_GZIP = 1, 2
 
 # every symbol include/defl/infl.h and include/defl/infl_batch.h declare
 EXPORTS = [
@@ -23,7 +24,7 @@ EXPORTS = [
     "infl_gpu_init", "infl_gpu_device_count", "infl_batch_dev", "infl_batch_dev_detail", "infl_batch",
     "infl_many", "infl_gpu_malloc", "infl_gpu_free", "infl_gpu_upload", "infl_gpu_download",
     "infl_gpu_sync", "infl_gpu_set_lanes_per_stream", "infl_gpu_set_table_variant",
-    "infl_batch_noalloc",
+    "infl_batch_noalloc", "infl_batch_dev_checked", "infl_batch_checked",
 ]
 
 
@@ -122,6 +123,8 @@ class Engine:
             "infl_batch_dev_detail": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp, vp]),
             "infl_batch": (i32, [vp, vp, vp, vp, i32, sz, vp, vp]),
             "infl_batch_noalloc": (i32, [vp, vp, vp, vp, i32, sz, vp, vp]),
+            "infl_batch_dev_checked": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp, vp, vp]),
+            "infl_batch_checked": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp]),
             "infl_many": (i32, [vp, sz, vp]),
             "infl_gpu_malloc": (vp, [sz]),
             "infl_gpu_free": (None, [vp]),
@@ -164,6 +167,22 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"infl_batch failed: {rc}")
         return dst, status[:n], outlen[:n]
+
+    def batch_checked(self, src, src_off, dst_off, check):
+        """infl_batch_checked() on host arrays -> (dst arena, status, outlen, detail)"""
+        n = len(src_off) - 1
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
+        dst_off = np.ascontiguousarray(dst_off, dtype=np.uint64)
+        dst = np.zeros(max(1, int(dst_off[-1])), dtype=np.uint8)
+        status = np.full(max(1, n), -99, dtype=np.int32)
+        outlen = np.zeros(max(1, n), dtype=np.uint32)
+        detail = np.full(max(1, n), -99, dtype=np.int32)
+        rc = self.lib.infl_batch_checked(src.ctypes.data, src_off.ctypes.data, dst.ctypes.data, dst_off.ctypes.data,
+                                         check, n, status.ctypes.data, outlen.ctypes.data, detail.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"infl_batch_checked failed: {rc}")
+        return dst, status[:n], outlen[:n], detail[:n]
 
     def device_batch(self, src, src_off, dst_off) -> DeviceBatch:
         return DeviceBatch(self, src, src_off, dst_off)

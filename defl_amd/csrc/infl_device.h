@@ -21,6 +21,14 @@ extern "C" {
 #define INFL_D_NEED_INPUT  2   /* input ended inside the stream             */
 #define INFL_D_FULL        3   /* output capacity reached                   */
 #define INFL_D_INTERNAL    4   /* safety counter ran out (engine bug)       */
+#define INFL_D_CHECKSUM    5   /* trailer mismatch (checked entry points)   */
+
+/* integrity passes of infl_launch_checked (values of infl_batch.h's INFL_CHECK_*) */
+#define INFL_CHECK_ADLER32 1
+#define INFL_CHECK_GZIP    2
+/* header lengths the gzip header pass leaves for streams without a usable header */
+#define INFL_SKIP_SHORT 0xfffffffeu   /* input ends inside the header */
+#define INFL_SKIP_BAD   0xffffffffu   /* not a gzip member            */
 
 /* status value the first (compact-table) pass leaves for a stream that the
    second pass has to decode; never visible to callers */
@@ -55,7 +63,8 @@ int infl_launch_resume(const void *src, uint32_t srclen, void *dst, uint32_t cap
 
 /* Enqueues the batch kernel; all pointers are device pointers; `detail` (why a
    stream stopped) and `inpos` (input bytes consumed) may be NULL.  lanes =
-   lanes of a wavefront per stream (64/32/16/8).  variant 0 = one launch with
+   lanes of a wavefront per stream (64/32/16/8).  `skip` (may be NULL): bytes in front of every
+   stream's DEFLATE data (a container header), inpos then counts from behind them.  variant 0 = one launch with
    tables in the reference's geometry; variant 1 = a first launch with compact
    16-bit tables (more streams in flight) plus a second launch in the
    reference's geometry for the streams the first one deferred; variant 2 = a
@@ -66,7 +75,13 @@ int infl_launch_resume(const void *src, uint32_t srclen, void *dst, uint32_t cap
 int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                       const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                       uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
-                      int variant, void *mirror, void *stream);
+                      int variant, void *mirror, void *stream, const uint32_t *skip);
+
+/* infl_launch_batch plus the integrity pass (see infl_batch_dev_checked in infl_batch.h);
+   work = 8 * n bytes of device memory. */
+int infl_launch_checked(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
+                        int check, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
+                        void *work, int lanes, int variant, void *mirror, void *stream);
 
 /* A pinned host buffer for gathering many streams' input before infl_rt_batch_host() (copies
    from pinned memory run at the full link rate).  One buffer per process: returns NULL when it is

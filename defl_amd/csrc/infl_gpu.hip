@@ -212,7 +212,7 @@ int infl_batch_dev(const void *dev_src, const uint64_t *dev_src_off, void *dev_d
   if (n == 0) return 0;
   if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen) return -1;
   return infl_launch_batch(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status,
-                           dev_outlen, nullptr, nullptr, g_lanes.load(), g_variant.load(), nullptr, hip_stream);
+                           dev_outlen, nullptr, nullptr, g_lanes.load(), g_variant.load(), nullptr, hip_stream, nullptr);
 }
 
 // Same with the per-stream detail codes (INFL_D_*); for tests and diagnosis.
@@ -222,7 +222,17 @@ int infl_batch_dev_detail(const void *dev_src, const uint64_t *dev_src_off, void
   if (n == 0) return 0;
   if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen) return -1;
   return infl_launch_batch(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status,
-                           dev_outlen, dev_detail, nullptr, g_lanes.load(), g_variant.load(), nullptr, hip_stream);
+                           dev_outlen, dev_detail, nullptr, g_lanes.load(), g_variant.load(), nullptr, hip_stream, nullptr);
+}
+
+int infl_batch_dev_checked(const void *dev_src, const uint64_t *dev_src_off, void *dev_dst,
+                           const uint64_t *dev_dst_off, int check, size_t n, int32_t *dev_status,
+                           uint32_t *dev_outlen, int32_t *dev_detail, void *dev_work, void *hip_stream) {
+  if (n == 0) return 0;
+  if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen || !dev_work) return -1;
+  if (check != INFL_CHECK_ADLER32 && check != INFL_CHECK_GZIP) return -1;
+  return infl_launch_checked(dev_src, dev_src_off, dev_dst, dev_dst_off, check, n, dev_status, dev_outlen,
+                             dev_detail, dev_work, g_lanes.load(), g_variant.load(), nullptr, hip_stream);
 }
 
 static Buf  g_pin;                 // see infl_rt_pinned_acquire
@@ -311,7 +321,7 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
     if (infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p,
                           flags, n, (int32_t *)w.status.p, (uint32_t *)w.outlen.p,
                           detail ? (int32_t *)w.detail.p : nullptr, inpos ? (uint32_t *)w.inpos.p : nullptr,
-                          lanes, variant, w.hdst.p, st) != 0) {
+                          lanes, variant, w.hdst.p, st, nullptr) != 0) {
       (void)hipStreamSynchronize(st);                    // the uploads queued above still read the caller's buffers
       return -1;
     }
@@ -412,7 +422,7 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
                                  flags, hi - lo, (int32_t *)w.status.p + lo, (uint32_t *)w.outlen.p + lo,
                                  detail ? (int32_t *)w.detail.p + lo : nullptr,
                                  inpos ? (uint32_t *)w.inpos.p + lo : nullptr, lanes, variant,
-                                 w.hdst.p, st) == 0;
+                                 w.hdst.p, st, nullptr) == 0;
     const size_t cnt = (hi - lo) * 4;
     ok &= hipMemcpyAsync(hm + lo, (int32_t *)w.status.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;
     ok &= hipMemcpyAsync(hm + n + lo, (uint32_t *)w.outlen.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;
@@ -543,7 +553,7 @@ int infl_batch_noalloc(const void *src, const uint64_t *src_off, void *dst, cons
   ok = ok && infl_launch_batch(base + kNaSrcAt, (const uint64_t *)(base + kNaSoffAt), base + kNaDstAt,
                                (const uint64_t *)(base + kNaDoffAt), flags == 1 ? 1 : 0, n,
                                (int32_t *)(base + kNaStatusAt), (uint32_t *)(base + kNaOutlenAt), nullptr, nullptr,
-                               g_lanes.load(), g_variant.load(), nullptr, st) == 0;
+                               g_lanes.load(), g_variant.load(), nullptr, st, nullptr) == 0;
   if (ok) {
     ok &= hipMemcpyAsync(status, base + kNaStatusAt, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
     ok &= hipMemcpyAsync(outlen, base + kNaOutlenAt, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
@@ -555,6 +565,51 @@ int infl_batch_noalloc(const void *src, const uint64_t *src_off, void *dst, cons
   if (!ok || !drained) {
     (void)hipGetLastError();
     return -1;
+  }
+  return 0;
+}
+
+// Host-memory form of infl_batch_dev_checked: upload, decode + integrity pass, download (one launch,
+// the device workspace of infl_batch(); only the bytes a stream produced are handed back).
+int infl_batch_checked(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
+                       int check, size_t n, int32_t *status, uint32_t *outlen, int32_t *detail) {
+  if (n == 0) return 0;
+  if (!src_off || !dst_off || !status || !outlen) return -1;
+  if (check != INFL_CHECK_ADLER32 && check != INFL_CHECK_GZIP) return -1;
+  if (!device_ready()) return -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
+  std::lock_guard<std::mutex> lock(g_mu[dev]);
+  Workspace &w = g_ws[dev];
+  const size_t src_bytes = (size_t)src_off[n], dst_bytes = (size_t)dst_off[n];
+  const size_t off_bytes = (n + 1) * sizeof(uint64_t);
+  if (!dev_reserve(w.src, src_bytes + 16) || !dev_reserve(w.dst, dst_bytes + 16) || !dev_reserve(w.soff, off_bytes) ||
+      !dev_reserve(w.doff, off_bytes) || !dev_reserve(w.status, n * 4) || !dev_reserve(w.outlen, n * 4) ||
+      !dev_reserve(w.detail, n * 4) || !dev_reserve(w.inpos, n * 8) || !host_reserve(w.hdst, dst_bytes + 16))
+    return -12;
+  hipStream_t st = nullptr;
+  bool ok = true;
+  if (src_bytes) ok &= hipMemcpyAsync(w.src.p, src, src_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(w.soff.p, src_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(w.doff.p, dst_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok = ok && infl_launch_checked(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p, check, n,
+                                 (int32_t *)w.status.p, (uint32_t *)w.outlen.p, (int32_t *)w.detail.p, w.inpos.p,
+                                 g_lanes.load(), g_variant.load(), nullptr, st) == 0;
+  if (ok) {
+    ok &= hipMemcpyAsync(status, w.status.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok &= hipMemcpyAsync(outlen, w.outlen.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (detail) ok &= hipMemcpyAsync(detail, w.detail.p, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (dst_bytes) ok &= hipMemcpyAsync(w.hdst.p, w.dst.p, dst_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+  }
+  const bool drained = hipStreamSynchronize(st) == hipSuccess;
+  if (!ok || !drained) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  for (size_t i = 0; i < n; i++) {
+    size_t len = outlen[i], cap = (size_t)(dst_off[i + 1] - dst_off[i]);
+    if (len > cap) len = cap;
+    if (len) memcpy((uint8_t *)dst + dst_off[i], (const uint8_t *)w.hdst.p + dst_off[i], len);
   }
   return 0;
 }

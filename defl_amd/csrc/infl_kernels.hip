@@ -1689,7 +1689,8 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
                                                         uint32_t *__restrict__ outlen,
                                                         int32_t *__restrict__ detail,
                                                         uint32_t *__restrict__ inpos,
-                                                        uint8_t *__restrict__ mirror) {
+                                                        uint8_t *__restrict__ mirror,
+                                                        const uint32_t *__restrict__ skip) {
   constexpr int  G    = 64 / T;                    // streams per wavefront
   constexpr int  SYM  = (MODE == 1 || MODE == 4) ? 1 : MODE == 3 ? 2 : 0;
   static_assert(MODE != 3 || T == 64, "the parallel block decoder uses the whole wavefront");
@@ -1716,6 +1717,10 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
 
   uint64_t s0 = src_off[i], s1 = src_off[i + 1];
   uint64_t d0 = dst_off[i], d1 = dst_off[i + 1];
+  if (skip) {                                        // a container header in front of the stream (gzip): not ours to decode
+    const uint64_t k = skip[i];
+    s0 = k < s1 - s0 ? s0 + k : s1;
+  }
   if constexpr (T == 64) {                           // one stream per wavefront: keep its bounds in scalar
     s0 = wave_uniform(s0);                           // registers, so that addresses are base + 32-bit offset
     s1 = wave_uniform(s1);
@@ -1856,6 +1861,250 @@ __global__ __launch_bounds__(64, 1) void infl_resume_kernel(const uint8_t *__res
   }
 }
 
+// ---------------------------------------------------------------------------
+// Opt-in integrity and framing.  The reference never looks at what follows the final block
+// (src/infl/zlib.h:45-96 reads the two header bytes only; no Adler-32 anywhere), so none of this
+// runs behind its ten functions: it belongs to entry points of its own (infl_batch_dev_checked).
+//   zlib (RFC 1950)  the Adler-32 of the output against the 4 bytes behind the final block;
+//   gzip (RFC 1952)  the member header is skipped by a pass of its own before the decode, then
+//                    CRC-32 and ISIZE (output length modulo 2^32) against the 8-byte trailer.
+// One wavefront per stream reads the stream's output once more, 16 bytes per lane and access.
+// Both sums are linear in the data, so every lane sums its own 16-byte chunks (one every 1024
+// bytes) and the 64 partial results are combined at the end.
+// ---------------------------------------------------------------------------
+constexpr uint32_t CRC_POLY = 0xEDB88320u;           // reflected CRC-32 polynomial: bit 31 is the x^0 term
+
+// product of two polynomials modulo the CRC polynomial (reflected representation)
+__device__ constexpr uint32_t crc_mul(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (int i = 0; i < 32; i++) {
+    if (a & (0x80000000u >> i)) p ^= b;
+    b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+  }
+  return p;
+}
+
+struct CrcTables {
+  uint32_t t[4][256];      // slicing-by-4 tables of the byte-wise update
+  uint32_t adv[4][256];    // a register moved over 1008 zero bytes (from one 16-byte chunk of a lane to its next)
+  uint32_t x2n[32];        // x^(2^k) modulo the polynomial
+};
+constexpr CrcTables make_crc_tables() {
+  CrcTables T{};
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+    T.t[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; i++)
+    for (int j = 1; j < 4; j++) T.t[j][i] = (T.t[j - 1][i] >> 8) ^ T.t[0][T.t[j - 1][i] & 0xffu];
+  T.x2n[0] = 0x40000000u;                              // x^1
+  for (int k = 1; k < 32; k++) T.x2n[k] = crc_mul(T.x2n[k - 1], T.x2n[k - 1]);
+  uint32_t xk = 0x80000000u;                           // x^(8 * 1008)
+  for (uint32_t n = 1008u, k = 3; n; n >>= 1, k++)
+    if (n & 1u) xk = crc_mul(T.x2n[k & 31u], xk);
+  for (int j = 0; j < 4; j++)
+    for (uint32_t b = 0; b < 256; b++) T.adv[j][b] = crc_mul(xk, b << (8 * j));
+  return T;
+}
+__constant__ const CrcTables c_crc = make_crc_tables();
+
+// x^(8 * nbytes) modulo the polynomial
+__device__ __forceinline__ uint32_t crc_xpow_bytes(uint64_t nbytes, const uint32_t *x2n) {
+  uint32_t p = 0x80000000u;
+  uint32_t k = 3;
+  for (uint64_t n = nbytes; n; n >>= 1, k++)
+    if (n & 1u) p = crc_mul(x2n[k & 31u], p);
+  return p;
+}
+
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v ^= (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u) ^ (uint32_t)d) << 2), (int)v);
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int      from = (int)(((threadIdx.x & 63u) ^ (uint32_t)d) << 2);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)(v >> 32));
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+
+// The lane's up to 16 bytes of the 1024-byte block that begins at p[base]: bytes [base + 16 * lane, ...) below n,
+// zero filled.  Returns how many of them are real.
+__device__ __forceinline__ uint32_t check_chunk(const uint8_t *p, uint64_t base, uint64_t n, int lane, uint32_t w[4]) {
+  const uint64_t at = base + 16u * (uint32_t)lane;
+  w[0] = w[1] = w[2] = w[3] = 0;
+  if (at + 16u <= n) {
+    uint4 q;
+    __builtin_memcpy(&q, p + at, 16);
+    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+    return 16u;
+  }
+  if (at >= n) return 0u;
+  const uint32_t k = (uint32_t)(n - at);
+  for (uint32_t j = 0; j < k; j++) w[j >> 2] |= (uint32_t)p[at + j] << (8u * (j & 3u));
+  return k;
+}
+
+// Adler-32 (RFC 1950) of p[0 .. n) by one wavefront.  a = 1 + sum of the bytes, b = n + sum of
+// (n - i) * byte i, both modulo 65521: every lane adds up its chunks with the weights reduced
+// modulo 65521 (64-bit sums, reduced once at the end).
+__device__ __forceinline__ uint32_t wave_adler32(const uint8_t *p, uint64_t n, int lane) {
+  constexpr uint32_t MOD = 65521u;
+  uint64_t A = 0, B = 0;
+  for (uint64_t base = 0; base < n; base += 1024u) {
+    uint32_t w[4];
+    if (check_chunk(p, base, n, lane, w) == 0) continue;
+    const uint64_t i0 = base + 16u * (uint32_t)lane;
+    const uint32_t w0 = (uint32_t)((n - i0) % MOD);
+    uint32_t s1 = 0, s2 = 0;                           // sum of the bytes, sum of j * byte j
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      s1 = __builtin_amdgcn_udot4(w[q], 0x01010101u, s1, false);
+      s2 = __builtin_amdgcn_udot4(w[q], 0x03020100u + 0x04040404u * (uint32_t)q, s2, false);
+    }
+    A += s1;
+    B += (uint64_t)w0 * s1 + (MOD - s2 % MOD);         // sum of (w0 - j) * byte j, kept non-negative
+  }
+  A = wave_sum64(A);
+  B = wave_sum64(B);
+  const uint32_t a = (uint32_t)((1u + A) % MOD), b = (uint32_t)((n % MOD + B) % MOD);
+  return (b << 16) | a;
+}
+
+// CRC-32 (RFC 1952) of p[0 .. n) by one wavefront; T = the tables in LDS.
+__device__ __forceinline__ uint32_t wave_crc32(const uint8_t *p, uint64_t n, int lane, const CrcTables &T) {
+  auto step4 = [&](uint32_t c, uint32_t word) {
+    c ^= word;
+    return T.t[3][c & 0xffu] ^ T.t[2][(c >> 8) & 0xffu] ^ T.t[1][(c >> 16) & 0xffu] ^ T.t[0][c >> 24];
+  };
+  const uint64_t full = n & ~(uint64_t)1023u;          // whole 1024-byte blocks: 16 bytes per lane each
+  uint32_t acc = 0;
+  for (uint64_t base = 0; base < full; base += 1024u) {
+    uint4 q;
+    __builtin_memcpy(&q, p + base + 16u * (uint32_t)lane, 16);
+    acc = T.adv[0][acc & 0xffu] ^ T.adv[1][(acc >> 8) & 0xffu] ^ T.adv[2][(acc >> 16) & 0xffu] ^ T.adv[3][acc >> 24];
+    acc = step4(step4(step4(step4(acc, q.x), q.y), q.z), q.w);
+  }
+  // behind a lane's last chunk of the whole blocks lie the chunks of the lanes above it, then the tail
+  const uint32_t tail = (uint32_t)(n - full);
+  uint32_t total = crc_mul(crc_xpow_bytes(16u * (63u - (uint32_t)lane) + tail, T.x2n), acc);
+  // the tail (under 1024 bytes): again up to 16 bytes per lane, byte by byte
+  {
+    uint32_t w[4];
+    const uint32_t k = check_chunk(p, full, n, lane, w);
+    uint32_t c = 0;
+    for (uint32_t j = 0; j < k; j++) c = T.t[0][(c ^ (w[j >> 2] >> (8u * (j & 3u)))) & 0xffu] ^ (c >> 8);
+    if (k) total ^= crc_mul(crc_xpow_bytes(tail - (16u * (uint32_t)lane + k), T.x2n), c);
+  }
+  total = wave_xor(total);
+  // the register starts at all ones (moved over the n bytes) and is inverted at the end
+  return total ^ crc_mul(crc_xpow_bytes(n, T.x2n), 0xffffffffu) ^ 0xffffffffu;
+}
+
+// gzip member header (RFC 1952 2.3): magic, CM = 8, flags, then the optional fields.  One lane per
+// stream.  skip[i] = bytes in front of the DEFLATE data, or INFL_SKIP_BAD / INFL_SKIP_SHORT.
+__global__ __launch_bounds__(256) void infl_gzip_header_kernel(const uint8_t *__restrict__ src,
+                                                              const uint64_t *__restrict__ src_off, uint64_t n,
+                                                              uint32_t *__restrict__ skip) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *p = src + src_off[i];
+  const uint64_t len = src_off[i + 1] - src_off[i];
+  uint32_t res = INFL_SKIP_SHORT;
+  do {
+    if (len < 10) {
+      if (len >= 1 && p[0] != 0x1f) res = INFL_SKIP_BAD;
+      if (len >= 2 && p[1] != 0x8b) res = INFL_SKIP_BAD;
+      if (len >= 3 && p[2] != 8) res = INFL_SKIP_BAD;
+      break;
+    }
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0u)) {   // reserved flag bits must be zero
+      res = INFL_SKIP_BAD;
+      break;
+    }
+    const uint32_t flg = p[3];
+    uint64_t at = 10;
+    if (flg & 4u) {                                  // FEXTRA: two length bytes, then that many
+      if (at + 2 > len) break;
+      at += 2u + (p[at] | ((uint32_t)p[at + 1] << 8));
+      if (at > len) break;
+    }
+    bool shortfall = false;
+    for (uint32_t f = 8u; f <= 16u && !shortfall; f <<= 1)   // FNAME, FCOMMENT: zero-terminated
+      if (flg & f) {
+        while (at < len && p[at]) at++;
+        if (at >= len) shortfall = true;
+        at++;
+      }
+    if (shortfall) break;
+    if (flg & 2u) at += 2;                           // FHCRC (not verified)
+    if (at > len || at > 0xfffffff0u) break;
+    res = (uint32_t)at;
+  } while (false);
+  skip[i] = res;
+}
+
+// Checks every stream that decoded: what = INFL_CHECK_ADLER32 or INFL_CHECK_GZIP.  inpos[i] = input bytes the
+// decode consumed (from the DEFLATE data's first byte on: the trailer begins there); skip as above (gzip only).
+template <int WHAT>
+__global__ __launch_bounds__(256) void infl_verify_kernel(const uint8_t *__restrict__ src, const uint64_t *__restrict__ src_off,
+                                                         const uint8_t *__restrict__ dst, const uint64_t *__restrict__ dst_off,
+                                                         uint64_t n, int32_t *__restrict__ status, uint32_t *__restrict__ outlen,
+                                                         int32_t *__restrict__ detail, const uint32_t *__restrict__ inpos,
+                                                         const uint32_t *__restrict__ skip) {
+  __shared__ CrcTables T;
+  if (WHAT == INFL_CHECK_GZIP) {
+    const uint32_t *from = (const uint32_t *)&c_crc;
+    for (uint32_t k = threadIdx.x; k < sizeof(CrcTables) / 4u; k += 256u) ((uint32_t *)&T)[k] = from[k];
+    __syncthreads();
+  }
+  const int      lane = threadIdx.x & 63;
+  const uint64_t i    = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const uint32_t hdr = WHAT == INFL_CHECK_GZIP ? skip[i] : 0u;
+  int32_t st = status[i], dt = st == 0 ? INFL_D_OK : detail ? detail[i] : INFL_D_INVALID;
+  uint32_t ol = outlen[i];
+  if (WHAT == INFL_CHECK_GZIP && hdr >= INFL_SKIP_SHORT) {                 // no usable header: nothing was decoded
+    st = -1;
+    dt = hdr == INFL_SKIP_BAD ? INFL_D_INVALID : INFL_D_NEED_INPUT;
+    ol = 0;
+  } else if (st == 0) {
+    const uint64_t s0 = src_off[i], len = src_off[i + 1] - s0, at = (uint64_t)hdr + inpos[i];
+    const uint32_t need = WHAT == INFL_CHECK_GZIP ? 8u : 4u;
+    const uint8_t *out = dst + dst_off[i];
+    if (at + need > len) {                           // the trailer is not all there
+      st = -1;
+      dt = INFL_D_NEED_INPUT;
+    } else {
+      const uint8_t *t = src + s0 + at;
+      bool good;
+      if (WHAT == INFL_CHECK_GZIP) {
+        const uint32_t want = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        good = wave_crc32(out, ol, lane, T) == want && isize == ol;
+      } else {
+        const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+        good = wave_adler32(out, ol, lane) == want;
+      }
+      if (!good) {
+        st = -1;
+        dt = INFL_D_CHECKSUM;
+      }
+    }
+  }
+  if (lane == 0) {
+    status[i] = st;
+    outlen[i] = ol;
+    if (detail) detail[i] = dt;
+  }
+}
+
 }  // namespace defl
 
 // variant 0: reference-geometry tables only (one launch).
@@ -1867,7 +2116,7 @@ __global__ __launch_bounds__(64, 1) void infl_resume_kernel(const uint8_t *__res
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                                  uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
-                                 int variant, void *mirror, void *stream) {
+                                 int variant, void *mirror, void *stream, const uint32_t *skip) {
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   auto s = (const uint8_t *)src;
@@ -1876,7 +2125,7 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
 #define LAUNCH(T, FMT, MODE)                                                                   \
   hipLaunchKernelGGL((defl::infl_batch_kernel<T, defl::FMT, MODE>),                            \
                      dim3((unsigned)((n + (64 / T) - 1) / (64 / T))), dim3(64), 0, st, s, src_off, \
-                     d, dst_off, flags, n, status, outlen, detail, inpos, m)
+                     d, dst_off, flags, n, status, outlen, detail, inpos, m, skip)
 #define LAUNCH_T(T)             \
   if (variant == 0) {           \
     LAUNCH(T, RefFmt, 0);       \
@@ -1899,6 +2148,32 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
   }
 #undef LAUNCH_T
 #undef LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// The decode of infl_launch_batch followed by the integrity pass: check = INFL_CHECK_ADLER32 (zlib streams) or
+// INFL_CHECK_GZIP (gzip members: a header pass first).  work = 8 * n bytes of device memory (consumed input
+// bytes and header lengths per stream).
+extern "C" int infl_launch_checked(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
+                                   int check, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
+                                   void *work, int lanes, int variant, void *mirror, void *stream) {
+  if (n == 0) return 0;
+  if (!work || (check != INFL_CHECK_ADLER32 && check != INFL_CHECK_GZIP)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t *inpos = (uint32_t *)work, *skip = inpos + n;
+  if (check == INFL_CHECK_GZIP)
+    hipLaunchKernelGGL(defl::infl_gzip_header_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const uint8_t *)src, src_off, n, skip);
+  if (infl_launch_batch(src, src_off, dst, dst_off, check == INFL_CHECK_ADLER32 ? 1 : 0, n, status, outlen, detail,
+                        inpos, lanes, variant, mirror, stream, check == INFL_CHECK_GZIP ? skip : nullptr) != 0)
+    return -1;
+  const dim3 grid((unsigned)((n + 3) / 4));
+  if (check == INFL_CHECK_GZIP)
+    hipLaunchKernelGGL((defl::infl_verify_kernel<INFL_CHECK_GZIP>), grid, dim3(256), 0, st, (const uint8_t *)src, src_off,
+                       (const uint8_t *)dst, dst_off, n, status, outlen, detail, inpos, skip);
+  else
+    hipLaunchKernelGGL((defl::infl_verify_kernel<INFL_CHECK_ADLER32>), grid, dim3(256), 0, st, (const uint8_t *)src, src_off,
+                       (const uint8_t *)dst, dst_off, n, status, outlen, detail, inpos, skip);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

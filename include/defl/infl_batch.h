@@ -77,6 +77,38 @@ infl_batch(const void *src, const uint64_t *src_off,
            int flags, size_t n, int32_t *status, uint32_t *outlen);
 
 /*
+ * Opt-in integrity and framing.  The reference stops at the final block: it never reads the zlib
+ * trailer (src/infl/zlib.h:45-96 parses the two header bytes only, src/infl/infl.c:1094-1101 hands
+ * the position back) and knows no gzip, so these checks are entry points of their own and the ten
+ * reference functions and the calls above keep the reference's behaviour bit for bit.
+ *   check = INFL_CHECK_ADLER32  streams are zlib streams (RFC 1950); after the decode the Adler-32
+ *                               of the output is compared with the four bytes behind the final block;
+ *   check = INFL_CHECK_GZIP     streams are gzip members (RFC 1952): the header (with its optional
+ *                               extra / name / comment / header-CRC fields) is skipped, and CRC-32
+ *                               and ISIZE of the output are compared with the eight trailer bytes.
+ * status[i] = UNZ_OK only if the stream decodes AND its trailer matches.  detail[i] (may be NULL)
+ * tells the rest: 0 fine, 1 malformed (also: not a gzip header), 2 input ended (also: inside the
+ * header or the trailer), 3 output capacity reached, 5 trailer mismatch; the output bytes of a
+ * stream whose trailer does not match stay in place, outlen[i] says how many.
+ * dev_work: 8 * n bytes of device memory for the call's own use.
+ */
+#define INFL_CHECK_ADLER32 1
+#define INFL_CHECK_GZIP    2
+UNZ_EXPORT int
+infl_batch_dev_checked(const void *dev_src, const uint64_t *dev_src_off,
+                       void *dev_dst, const uint64_t *dev_dst_off,
+                       int check, size_t n,
+                       int32_t *dev_status, uint32_t *dev_outlen, int32_t *dev_detail,
+                       void *dev_work, void *hip_stream);
+
+/* The same for arenas in host memory (upload, decode and check, download). */
+UNZ_EXPORT int
+infl_batch_checked(const void *src, const uint64_t *src_off,
+                   void *dst, const uint64_t *dst_off,
+                   int check, size_t n,
+                   int32_t *status, uint32_t *outlen, int32_t *detail);
+
+/*
  * infl_batch() for callers that cannot allocate: tight serving loops, harnesses that forbid
  * hipMalloc, code that runs while a HIP graph is being captured elsewhere in the process.  It has
  * no counterpart in the reference.  Same arguments and results as infl_batch(), but the device

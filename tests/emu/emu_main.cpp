@@ -20,7 +20,8 @@ struct Group {
   std::atomic<uint64_t> mask[3];
   Group() { for (auto &m : mask) m.store(0); }
 };
-int g_slots[2][64];   // ds_bpermute exchange buffers, one slot per lane of the wavefront
+int g_slots[2][1024];   // ds_bpermute exchange buffers, one slot per thread of the workgroup (read within the wavefront)
+pthread_barrier_t *g_block_bar = nullptr;   // __syncthreads of the workgroup that is running
 thread_local dim3     t_threadIdx, t_blockIdx;
 thread_local Group   *t_group = nullptr;
 thread_local int      t_lane  = 0;
@@ -28,13 +29,14 @@ thread_local unsigned t_ballots = 0, t_permutes = 0;
 int                   g_lanes_per_group = 64;
 
 void group_barrier() { pthread_barrier_wait(&t_group->bar); }
+void block_barrier() { pthread_barrier_wait(g_block_bar); }
 
 uint64_t ballot(bool pred) {
   const unsigned k = t_ballots++ % 3u;
   // the buffer of the next ballot was last read two ballots ago: every lane has since arrived at
   // the barrier of the ballot before this one, and none writes it before this ballot's barrier
   if (t_lane % g_lanes_per_group == 0) t_group->mask[(k + 1u) % 3u].store(0);
-  if (pred) t_group->mask[k].fetch_or(1ull << t_lane);
+  if (pred) t_group->mask[k].fetch_or(1ull << (t_lane & 63));
   group_barrier();
   return t_group->mask[k].load();
 }
@@ -44,7 +46,7 @@ int bpermute(int byte_addr, int value) {
   const unsigned k = t_permutes++ & 1u;          // (the other buffer may still be read by slower lanes)
   g_slots[k][t_lane] = value;
   group_barrier();
-  return g_slots[k][(byte_addr >> 2) & 63];
+  return g_slots[k][(t_lane & ~63) + ((byte_addr >> 2) & 63)];
 }
 
 void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
@@ -52,6 +54,9 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
   for (unsigned b = 0; b < grid; b++) {
     std::vector<Group> groups(ngroups);
     for (auto &g : groups) pthread_barrier_init(&g.bar, nullptr, T);
+    pthread_barrier_t block_bar;
+    pthread_barrier_init(&block_bar, nullptr, block);
+    g_block_bar = &block_bar;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < block; t++)
       th.emplace_back([&, t] {
@@ -64,6 +69,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
       });
     for (auto &x : th) x.join();
     for (auto &g : groups) pthread_barrier_destroy(&g.bar);
+    pthread_barrier_destroy(&block_bar);
   }
 }
 }  // namespace emu
@@ -81,7 +87,7 @@ extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *ds
   if (variant >= 2) lanes = 64;   // the parallel pass is a 64-lane kernel; one group size per run here
   emu::g_lanes_per_group = lanes;
   return infl_launch_batch(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, variant,
-                           mirror, nullptr);
+                           mirror, nullptr, nullptr);
 }
 
 // emu_run <in.bin> <out.bin> <lanes> <flags> <variant> [plain]
@@ -158,9 +164,18 @@ int main(int argc, char **argv) {
   uint8_t *mirror = (uint8_t *)malloc(dof[n] ? dof[n] : 1);
   memset(mirror, 0x5a, dof[n] ? dof[n] : 1);
   const bool plain = argc > 6 && atoi(argv[6]) != 0;   // no detail codes, no input positions asked for
-  int rc = emu_infl_batch(src, so.data(), dst, dof.data(), atoi(argv[4]), n, status.data(), outlen.data(),
-                          plain ? nullptr : detail.data(), plain ? nullptr : inpos.data(), atoi(argv[3]),
-                          atoi(argv[5]), mirror);
+  const int  check = argc > 7 ? atoi(argv[7]) : 0;     // the decode followed by the integrity pass (flags are ignored)
+  int rc;
+  if (check) {
+    std::vector<uint32_t> work(2 * n + 2);
+    emu::g_lanes_per_group = 64;
+    rc = infl_launch_checked(src, so.data(), dst, dof.data(), check, n, status.data(), outlen.data(), detail.data(),
+                             work.data(), 64, atoi(argv[5]), mirror, nullptr);
+  } else {
+    rc = emu_infl_batch(src, so.data(), dst, dof.data(), atoi(argv[4]), n, status.data(), outlen.data(),
+                        plain ? nullptr : detail.data(), plain ? nullptr : inpos.data(), atoi(argv[3]),
+                        atoi(argv[5]), mirror);
+  }
   if (rc != 0) return 3;
   for (uint64_t i = 0; i < n; i++) {                 // exactly the produced bytes, nothing around them
     const uint64_t a = dof[i], e = dof[i + 1];

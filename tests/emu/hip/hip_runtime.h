@@ -33,6 +33,7 @@ extern thread_local dim3   t_threadIdx, t_blockIdx;
 extern thread_local Group *t_group;
 extern thread_local int    t_lane;
 void     group_barrier();
+void     block_barrier();
 uint64_t ballot(bool pred);
 int      bpermute(int byte_addr, int value);
 void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
@@ -46,6 +47,12 @@ void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 
 #define __builtin_amdgcn_fence(order, scope) emu::group_barrier()
 #define __builtin_amdgcn_wave_barrier() emu::group_barrier()
+#define __syncthreads() emu::block_barrier()
+// v_dot4_u32_u8: c + the four byte products of a and b
+static inline uint32_t __builtin_amdgcn_udot4(uint32_t a, uint32_t b, uint32_t c, bool) {
+  for (int k = 0; k < 4; k++) c += ((a >> (8 * k)) & 0xffu) * ((b >> (8 * k)) & 0xffu);
+  return c;
+}
 #define __ballot(p) emu::ballot(p)
 #define __popcll(x) __builtin_popcountll(x)
 #define __builtin_amdgcn_ds_bpermute(a, v) emu::bpermute(a, v)

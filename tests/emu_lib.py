@@ -14,7 +14,7 @@ def build():
     subprocess.check_call(["make", "-s", "-C", EMU_DIR])
 
 
-def run(src, src_off, dst_off, flags=0, lanes=64, variant=0, timeout=600, plain=False):
+def run(src, src_off, dst_off, flags=0, lanes=64, variant=0, timeout=600, plain=False, check=0):
     build()
     n = len(src_off) - 1
     src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
@@ -25,7 +25,7 @@ def run(src, src_off, dst_off, flags=0, lanes=64, variant=0, timeout=600, plain=
         with open(fin, "wb") as f:
             f.write(np.uint64(n).tobytes() + src_off.tobytes() + dst_off.tobytes() + src.tobytes())
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
-        p = subprocess.run([EXE, fin, fout, str(lanes), str(flags), str(variant), "1" if plain else "0"],
+        p = subprocess.run([EXE, fin, fout, str(lanes), str(flags), str(variant), "1" if plain else "0", str(check)],
                            env=env, timeout=timeout,
                            capture_output=True, text=True)
         if p.returncode != 0:

@@ -216,3 +216,66 @@ def test_emulated_incremental_kernel(oracle):
     assert status[0] == 0 and dst[:len(text)].tobytes() == text
     assert status[1] == 3 and 0 < outlen[1] <= 100 and dst[len(text):len(text) + int(outlen[1])].tobytes() == text[:int(outlen[1])]
     assert status[2] == 1
+
+
+def _gzip_member(raw, name=b"", comment=b"", extra=b"", hcrc=False, level=6):
+    """A gzip member (RFC 1952) with the optional header fields asked for."""
+    flg = (4 if extra else 0) | (8 if name else 0) | (16 if comment else 0) | (2 if hcrc else 0)
+    hdr = bytes([0x1f, 0x8b, 8, flg, 1, 2, 3, 4, 0, 3])
+    if extra:
+        hdr += len(extra).to_bytes(2, "little") + extra
+    if name:
+        hdr += name + b"\0"
+    if comment:
+        hdr += comment + b"\0"
+    if hcrc:
+        hdr += (zlib.crc32(hdr) & 0xffff).to_bytes(2, "little")
+    body = wl.deflate(raw, level, False)
+    return hdr + body + (zlib.crc32(raw) & 0xffffffff).to_bytes(4, "little") + (len(raw) & 0xffffffff).to_bytes(4, "little")
+
+
+def test_emulated_integrity_passes():
+    """The opt-in checks behind infl_batch_dev_checked on the CPU: Adler-32 of zlib streams and gzip
+    framing (header fields skipped, CRC-32 and ISIZE) against Python's zlib; damaged and missing
+    trailers are told apart (detail 5 = checksum mismatch, 2 = input ended)."""
+    rng = random.Random(85)
+    raws = [b"", b"a", b"abc" * 7, wl.text_stream(41, 1023), wl.text_stream(42, 1024), wl.text_stream(43, 1025),
+            wl.text_stream(44, 5000), bytes(rng.randrange(256) for _ in range(3333)), bytes(2500)]
+    # zlib + Adler-32
+    good = [wl.deflate(r) for r in raws]
+    assert all(int.from_bytes(c[-4:], "big") == zlib.adler32(r) for c, r in zip(good, raws))
+    bad = []
+    for c in good[3:6]:
+        b = bytearray(c); b[-2] ^= 0x40; bad.append(bytes(b))           # wrong trailer
+    short = [good[6][:-1], good[6][:-4]]                                   # trailer cut
+    body = bytearray(good[7]); body[len(body) // 2] ^= 1                   # damaged data: whatever it decodes to, never OK with this trailer
+    streams = good + bad + short + [bytes(body)]
+    caps = [len(r) for r in raws] + [len(r) for r in raws[3:6]] + [5000, 5000, 3333 + 64]
+    src, so, do = wl.pack(streams, caps)
+    dst, status, outlen, detail, _ = emu_lib.run(src, so, do, 1, 64, 2, check=1)
+    for i, r in enumerate(raws):
+        assert status[i] == 0 and outlen[i] == len(r) and detail[i] == 0, (i, int(status[i]), int(detail[i]))
+        assert dst[int(do[i]):int(do[i]) + len(r)].tobytes() == r
+    k = len(raws)
+    assert list(status[k:k + 3]) == [-1] * 3 and list(detail[k:k + 3]) == [5] * 3
+    assert list(status[k + 3:k + 5]) == [-1, -1] and list(detail[k + 3:k + 5]) == [2, 2]
+    assert status[k + 5] == -1
+    # gzip
+    members = [_gzip_member(raws[0]), _gzip_member(raws[2], name=b"file.txt"), _gzip_member(raws[3], comment=b"c" * 40, hcrc=True),
+               _gzip_member(raws[4], extra=b"\x01\x02" * 9, name=b"n"), _gzip_member(raws[5], level=1), _gzip_member(raws[6]),
+               _gzip_member(raws[7], name=b"x", comment=b"y", extra=b"zzzz", hcrc=True)]
+    mraws = [raws[0], raws[2], raws[3], raws[4], raws[5], raws[6], raws[7]]
+    b1 = bytearray(members[5]); b1[-6] ^= 2                                # CRC-32 wrong
+    b2 = bytearray(members[5]); b2[-1] ^= 1                                # ISIZE wrong
+    extra = [bytes(b1), bytes(b2), members[5][:-3], members[3][:14], b"\x1f\x8b\x07" + members[1][3:], good[3], b""]
+    streams = members + extra
+    caps = [len(r) for r in mraws] + [5000, 5000, 5000, 1024, 21, 1023, 10]
+    src, so, do = wl.pack(streams, caps)
+    dst, status, outlen, detail, _ = emu_lib.run(src, so, do, 0, 64, 2, check=2)
+    for i, r in enumerate(mraws):
+        assert status[i] == 0 and outlen[i] == len(r), (i, int(status[i]), int(detail[i]))
+        assert dst[int(do[i]):int(do[i]) + len(r)].tobytes() == r
+    k = len(members)
+    assert list(status[k:]) == [-1] * 7
+    assert list(detail[k:k + 2]) == [5, 5] and detail[k + 2] == 2 and detail[k + 3] == 2     # mismatches; trailer / header cut
+    assert detail[k + 4] == 1 and detail[k + 5] == 1 and detail[k + 6] == 2                   # not gzip (twice); nothing there
