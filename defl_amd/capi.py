@@ -24,7 +24,7 @@ EXPORTS = [
     "infl_gpu_init", "infl_gpu_device_count", "infl_batch_dev", "infl_batch_dev_detail", "infl_batch",
     "infl_many", "infl_gpu_malloc", "infl_gpu_free", "infl_gpu_upload", "infl_gpu_download",
     "infl_gpu_sync", "infl_gpu_set_lanes_per_stream", "infl_gpu_set_table_variant",
-    "infl_batch_noalloc", "infl_batch_dev_checked", "infl_batch_checked",
+    "infl_batch_noalloc", "infl_batch_dev_checked", "infl_batch_checked", "infl_png_unfilter_dev",
 ]
 
 
@@ -125,6 +125,7 @@ class Engine:
             "infl_batch_noalloc": (i32, [vp, vp, vp, vp, i32, sz, vp, vp]),
             "infl_batch_dev_checked": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp, vp, vp]),
             "infl_batch_checked": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp]),
+            "infl_png_unfilter_dev": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]),
             "infl_many": (i32, [vp, sz, vp]),
             "infl_gpu_malloc": (vp, [sz]),
             "infl_gpu_free": (None, [vp]),
@@ -183,6 +184,38 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"infl_batch_checked failed: {rc}")
         return dst, status[:n], outlen[:n], detail[:n]
+
+    def png_unfilter(self, batch: "DeviceBatch", geom, chained=True):
+        """infl_png_unfilter_dev() behind a decoded DeviceBatch: image i is the output of stream i, geom a list
+        of (rows, rowbytes, bpp).  chained = pass the decode's outlen and status along.
+        -> (list of per-image bytes, status)"""
+        lib, n = self.lib, batch.n
+        g = np.zeros((max(1, n), 4), dtype=np.uint32)
+        for i, (rows, rowbytes, bpp) in enumerate(geom):
+            g[i, :3] = rows, rowbytes, bpp
+        ooff = np.zeros(n + 1, dtype=np.uint64)
+        ooff[1:] = np.cumsum([int(r) * int(rb) for r, rb, _ in geom], dtype=np.uint64)
+        total = int(ooff[-1])
+        d_geom, d_ooff, d_out, d_st = (lib.infl_gpu_malloc(x) for x in (g.nbytes, ooff.nbytes, total + 16, 4 * max(1, n)))
+        try:
+            if not all((d_geom, d_ooff, d_out, d_st)):
+                raise MemoryError("infl_gpu_malloc failed")
+            assert lib.infl_gpu_upload(d_geom, g.ctypes.data, g.nbytes) == 0
+            assert lib.infl_gpu_upload(d_ooff, ooff.ctypes.data, ooff.nbytes) == 0
+            rc = lib.infl_png_unfilter_dev(batch.d_dst, batch.d_doff, batch.d_outlen if chained else None,
+                                           batch.d_status if chained else None, d_out, d_ooff, d_geom, n, d_st, None)
+            if rc != 0:
+                raise RuntimeError("infl_png_unfilter_dev failed to launch")
+            assert lib.infl_gpu_sync() == 0
+            out = np.zeros(max(1, total), dtype=np.uint8)
+            st = np.zeros(max(1, n), dtype=np.int32)
+            assert lib.infl_gpu_download(out.ctypes.data, d_out, total) == 0
+            assert lib.infl_gpu_download(st.ctypes.data, d_st, 4 * n) == 0
+        finally:
+            for p in (d_geom, d_ooff, d_out, d_st):
+                if p:
+                    lib.infl_gpu_free(p)
+        return [out[int(ooff[i]):int(ooff[i + 1])].tobytes() for i in range(n)], st[:n]
 
     def device_batch(self, src, src_off, dst_off) -> DeviceBatch:
         return DeviceBatch(self, src, src_off, dst_off)

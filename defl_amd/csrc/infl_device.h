@@ -83,6 +83,18 @@ int infl_launch_checked(const void *src, const uint64_t *src_off, void *dst, con
                         int check, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
                         void *work, int lanes, int variant, void *mirror, void *stream);
 
+/* Enqueues the PNG un-filter pass (see infl_png_unfilter_dev in infl_batch.h, which holds the same
+   definition of InflPngGeom). */
+#ifndef INFL_PNG_GEOM_DEFINED
+#define INFL_PNG_GEOM_DEFINED
+typedef struct InflPngGeom {
+  uint32_t rows, rowbytes, bpp, reserved;
+} InflPngGeom;
+#endif
+int infl_launch_png_unfilter(const void *in, const uint64_t *in_off, const uint32_t *in_len,
+                             const int32_t *in_status, void *out, const uint64_t *out_off,
+                             const InflPngGeom *geom, uint64_t n, int32_t *status, void *stream);
+
 /* A pinned host buffer for gathering many streams' input before infl_rt_batch_host() (copies
    from pinned memory run at the full link rate).  One buffer per process: returns NULL when it is
    in use, when no device is usable or when pinning fails; the caller then uses ordinary memory.

@@ -235,6 +235,15 @@ int infl_batch_dev_checked(const void *dev_src, const uint64_t *dev_src_off, voi
                              dev_detail, dev_work, g_lanes.load(), g_variant.load(), nullptr, hip_stream);
 }
 
+int infl_png_unfilter_dev(const void *dev_in, const uint64_t *dev_in_off, const uint32_t *dev_in_len,
+                          const int32_t *dev_in_status, void *dev_out, const uint64_t *dev_out_off,
+                          const InflPngGeom *dev_geom, size_t n, int32_t *dev_status, void *hip_stream) {
+  if (n == 0) return 0;
+  if (!dev_in || !dev_in_off || !dev_out || !dev_out_off || !dev_geom || !dev_status) return -1;
+  return infl_launch_png_unfilter(dev_in, dev_in_off, dev_in_len, dev_in_status, dev_out, dev_out_off, dev_geom, n,
+                                  dev_status, hip_stream);
+}
+
 static Buf  g_pin;                 // see infl_rt_pinned_acquire
 static bool g_pin_busy = false;
 static std::mutex g_pin_mu;

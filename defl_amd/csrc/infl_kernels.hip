@@ -26,6 +26,7 @@
 // like every HIP source of this library (see the Makefile).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "infl_device.h"
 
@@ -2105,6 +2106,312 @@ __global__ __launch_bounds__(256) void infl_verify_kernel(const uint8_t *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// PNG un-filter: the step that follows inflate in a PNG decoder (the reference names it as its
+// caller's job, README.md:150-152; the rule itself is the PNG specification's, section 9).  Every
+// scanline arrives as one filter-type byte and rowbytes filtered bytes; a byte is rebuilt from the
+// byte bpp to its left (a), the byte above (b) and the byte above a (c).
+//
+// One wavefront per image, one lane per scanline, 64 scanlines in flight as a diagonal: at step t
+// lane l rebuilds byte x = t - l of its row, so the byte above it left lane l-1 one step earlier
+// (one DPP shift brings it over) and a and c are values the lane itself had bpp steps earlier.
+// Memory moves in windows of PNG_WIN steps through an LDS tile, in pieces of 16 bytes: PNG_WIN / 16
+// lanes cover one scanline's window, so one load instruction brings the windows of several
+// scanlines, coalesced (a lane reading its own row from memory instead touches 64 cache lines per
+// instruction, and the lines are evicted between touches: 3 x the traffic, measured).  The lanes then
+// run down their tile rows 16 bytes at a time, write the rebuilt bytes over the filtered ones, and the
+// tile goes back to memory the way it came.  While a window is being rebuilt the next one's bytes are
+// already on their way from memory into registers.  Rows beyond the first 64 follow in bands; lane 0
+// of a later band gets the last row of the band before from the output (tile row 64).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t PNG_WIN    = 256;                  // steps (= bytes of every scanline) per window
+constexpr uint32_t PNG_PIECES = PNG_WIN / 16;         // lanes that cover one scanline's window
+constexpr uint32_t PNG_RPI    = 64 / PNG_PIECES;      // scanlines per load / store instruction
+constexpr uint32_t PNG_NI     = 64 / PNG_RPI;         // such instructions per window
+constexpr uint32_t PNG_PITCH  = PNG_WIN + 16;         // tile row pitch in bytes: 16-byte accesses of 16 lanes in a row or in a
+                                                      // column spread over all banks (pitch / 4 = 4 mod 8)
+static_assert(PNG_WIN == 256 || PNG_WIN == 128, "pitch and bank layout are worked out for these");
+
+struct __attribute__((packed)) PngPiece { uint32_t w[4]; };          // 16 bytes at any address
+struct __attribute__((aligned(16))) PngPiece16 { uint32_t w[4]; };   // in the tile
+
+// 16 bytes at p, any alignment; what lies outside [lo, hi) reads as 0.
+__device__ __forceinline__ PngPiece16 png_load16_guarded(const uint8_t *p, const uint8_t *lo, const uint8_t *hi) {
+  PngPiece16 c = {{0, 0, 0, 0}};
+#pragma unroll
+  for (int j = 0; j < 16; j++)
+    if (p + j >= lo && p + j < hi) c.w[j >> 2] |= (uint32_t)p[j] << (8 * (j & 3));
+  return c;
+}
+
+__device__ __forceinline__ uint32_t png_piece_byte(const PngPiece &p, uint32_t j) {   // byte j of 16, no indexed registers
+  const uint32_t w = j < 8 ? (j < 4 ? p.w[0] : p.w[1]) : (j < 12 ? p.w[2] : p.w[3]);
+  return (w >> (8u * (j & 3u))) & 0xffu;
+}
+
+// v of lane l-1; lane 0 keeps `first`
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t first, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// The last bytes of a lane's own row (a comes from there) and of the row above it (c): BPP known at compile time =
+// the values of the last BPP steps by name, no shifting; BPP = 0 = any bpp of 1..8 at run time, two 8-byte shift
+// registers.
+template <int BPP>
+struct PngPast {
+  uint32_t own[BPP], above[BPP];
+  __device__ __forceinline__ void clear(uint32_t) {
+#pragma unroll
+    for (int j = 0; j < BPP; j++) own[j] = above[j] = 0;
+  }
+};
+template <>
+struct PngPast<0> {
+  uint64_t own, above;
+  uint32_t sh;
+  __device__ __forceinline__ void clear(uint32_t bpp) {
+    own = above = 0;
+    sh  = 8u * (bpp - 1u);
+  }
+};
+
+// One image (geometry checked by the caller: rows >= 1, rb >= 1, need_in < 2^32 - 1024); true if a scanline names a filter
+// type above 4.  The windows of all bands form one sequence.
+template <int BPP>
+__device__ __forceinline__ bool png_unfilter_image(uint8_t *tile, const uint8_t *ib, uint32_t need_in, uint8_t *ob,
+                                                   uint32_t rows, uint32_t rb, uint32_t bpp, uint32_t lane) {
+  const uint32_t pitch = rb + 1u;
+  const uint32_t steps = rb + 63u;                   // until lane 63 has finished its row
+  const bool     fast  = rb >= 16;
+  const uint32_t sub = lane / PNG_PIECES, piece = lane % PNG_PIECES;   // this lane's part in a load / store instruction
+  bool bad = false;
+  // Tile row q, byte j = byte x = t0 - q + j of scanline r0 + q (x wraps to a large number left of the row; the
+  // address stays inside the image all the same: scanline r0 + q starts at least q + 1 bytes into it).  No branch
+  // per load, so that all of them are in flight together: a piece that would reach past the image is read from the
+  // image's last 16 bytes instead.  With rows of 16 bytes or more the only bytes of such a piece that anyone uses
+  // are the last 15 of the last row: those are put right from `tail` once the tile is written.
+  PngPiece nxt[PNG_NI], nxt_up = {{0, 0, 0, 0}}, tail = {{0, 0, 0, 0}}, up_tail = {{0, 0, 0, 0}};
+  uint32_t nxt_ft;
+  if (fast) tail = *(const PngPiece *)(ib + (need_in - 16u));
+#define PNG_FETCH(R0, T0)                                                                            \
+  if (fast) {                                                                                        \
+    const uint32_t nr_ = rows - (R0) < 64u ? rows - (R0) : 64u, xl_ = (T0) + 16u * piece + 1u;        \
+    _Pragma("unroll") for (uint32_t u_ = 0; u_ < PNG_NI; u_++) {                                     \
+      const uint32_t q_ = u_ * PNG_RPI + sub, qq_ = q_ < nr_ ? q_ : nr_ - 1u;                        \
+      const uint32_t at_ = ((R0) + qq_) * pitch - qq_ + xl_;                                         \
+      nxt[u_] = *(const PngPiece *)(ib + (at_ < need_in - 16u ? at_ : need_in - 16u));               \
+    }                                                                                                \
+  }
+  PNG_FETCH(0u, 0u)
+  nxt_ft = lane < rows ? ib[lane * pitch] : 0u;
+  uint32_t r0 = 0, t0 = 0, ft = 0, m_sub = 0, m_up = 0, m_avg = 0, m_paeth = 0, prev = 0;
+  PngPast<BPP> past;
+  past.clear(bpp);
+  for (;;) {
+    const uint32_t nrow = rows - r0 < 64u ? rows - r0 : 64u;
+    const uint8_t *up = r0 ? ob + (uint64_t)(r0 - 1u) * rb : nullptr;   // the row above lane 0's
+    if (t0 == 0) {                                   // a new band
+      ft = nxt_ft;
+      if (ft > 4) {
+        bad = true;
+        ft  = 0;
+      }
+      // the predictor is picked with masks, not branches: the lanes of a wavefront rarely agree on the filter type
+      m_sub = ft == 1 ? 0xffu : 0u, m_up = ft == 2 ? 0xffu : 0u, m_avg = ft == 3 ? 0xffu : 0u, m_paeth = ft == 4 ? 0xffu : 0u;
+      past.clear(bpp);
+      prev = 0;
+      // the band before has just been written: its last row is this band's row above
+      if (up && fast && lane < 16) {
+        const uint32_t at = 16u * lane;
+        if (lane < PNG_PIECES) nxt_up = *(const PngPiece *)(up + (at < rb - 16u ? at : rb - 16u));
+        up_tail = *(const PngPiece *)(up + (rb - 16u));
+      }
+    }
+    if (fast) {
+#pragma unroll
+      for (uint32_t u = 0; u < PNG_NI; u++) {
+        PngPiece16 v = {{nxt[u].w[0], nxt[u].w[1], nxt[u].w[2], nxt[u].w[3]}};
+        *(PngPiece16 *)(tile + (u * PNG_RPI + sub) * PNG_PITCH + 16u * piece) = v;
+      }
+      if (lane < PNG_PIECES) {
+        PngPiece16 v = {{nxt_up.w[0], nxt_up.w[1], nxt_up.w[2], nxt_up.w[3]}};
+        *(PngPiece16 *)(tile + 64u * PNG_PITCH + 16u * lane) = v;
+      }
+    } else {                                         // rows of fewer than 16 bytes: no hurry
+      for (uint32_t q = sub; q < nrow; q += PNG_RPI)
+        *(PngPiece16 *)(tile + q * PNG_PITCH + 16u * piece) =
+            png_load16_guarded(ib + (r0 + q) * pitch + 1u + (int64_t)(int32_t)(t0 + 16u * piece - q), ib, ib + need_in);
+      if (lane < PNG_PIECES) {
+        PngPiece16 v = {{0, 0, 0, 0}};
+        if (up) v = png_load16_guarded(up + t0 + 16u * lane, up, up + rb);
+        *(PngPiece16 *)(tile + 64u * PNG_PITCH + 16u * lane) = v;
+      }
+    }
+    group_sync();
+    if (fast && lane < 15) {                         // the last 15 bytes of the image and of the row above
+      const uint32_t x = rb - 1u - lane;
+      if (r0 + nrow == rows) {
+        const uint32_t off = x - (t0 - (nrow - 1u));
+        if (off < PNG_WIN) tile[(nrow - 1u) * PNG_PITCH + off] = (uint8_t)png_piece_byte(tail, 15u - lane);
+      }
+      if (up && x - t0 < PNG_WIN)
+        tile[64u * PNG_PITCH + (x - t0)] = (uint8_t)png_piece_byte(up_tail, 15u - lane);
+    }
+    group_sync();
+    // start on the next window's bytes
+    const bool     more_here = t0 + PNG_WIN < steps, more = more_here || r0 + 64u < rows;
+    const uint32_t r0n = more_here ? r0 : r0 + 64u, t0n = more_here ? t0 + PNG_WIN : 0u;
+    if (more) {
+      PNG_FETCH(r0n, t0n)
+      if (more_here) {
+        if (up && fast && lane < PNG_PIECES) {
+          const uint32_t at = t0n + 16u * lane;
+          nxt_up = *(const PngPiece *)(up + (at < rb - 16u ? at : rb - 16u));
+        }
+      } else {
+        nxt_ft = r0n + lane < rows ? ib[(r0n + lane) * pitch] : 0u;
+      }
+    }
+    if (t0 == 0) {
+      // What lies left of a row (steps before the lane's first) must rebuild to 0, so that a and c of the first
+      // pixel are 0: zero it here (0 filtered + predictor 0 = 0) instead of testing the position at every step.
+      uint32_t *mine = (uint32_t *)(tile + lane * PNG_PITCH);
+#pragma unroll
+      for (uint32_t w = 0; w < 16; w++) {
+        const uint32_t nz = lane > 4u * w ? lane - 4u * w : 0u;         // bytes of this dword left of the row
+        if (nz) mine[w] = nz >= 4u ? 0u : mine[w] & (~0u << (8u * nz));
+      }
+    }
+    group_sync();
+    const uint32_t nchunk = steps - t0 < PNG_WIN ? (steps - t0 + 15u) / 16u : PNG_WIN / 16u;
+    for (uint32_t k = 0; k < nchunk; k++) {
+      const PngPiece16 cur = *(const PngPiece16 *)(tile + lane * PNG_PITCH + 16u * k),
+                       upc = *(const PngPiece16 *)(tile + 64u * PNG_PITCH + 16u * k);
+      PngPiece16 o = {{0, 0, 0, 0}};
+      uint32_t byte[16], bu[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t v = (cur.w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+        bu[j] = from_lane_below((upc.w[j >> 2] >> (8 * (j & 3))) & 0xffu, prev);
+        uint32_t a, c;
+        if constexpr (BPP != 0) {
+          a = j >= BPP ? byte[j >= BPP ? j - BPP : 0] : past.own[j < BPP ? j : 0];
+          c = j >= BPP ? bu[j >= BPP ? j - BPP : 0] : past.above[j < BPP ? j : 0];
+        } else {
+          a = (uint32_t)(past.own >> past.sh) & 0xffu;
+          c = (uint32_t)(past.above >> past.sh) & 0xffu;
+        }
+        const uint32_t b = bu[j], ab = a + b;
+        const uint32_t pa = __builtin_amdgcn_sad_u8(b, c, 0), pb = __builtin_amdgcn_sad_u8(a, c, 0),
+                       pc = __builtin_amdgcn_sad_u16(ab, c << 1, 0);            // |a + b - 2c|, both sides below 2^16
+        const uint32_t paeth = pa <= (pb < pc ? pb : pc) ? a : pb <= pc ? b : c;
+        const uint32_t pred = (a & m_sub) | (b & m_up) | ((ab >> 1) & m_avg) | (paeth & m_paeth);
+        byte[j] = (v + pred) & 0xffu;
+        prev = byte[j];
+        if constexpr (BPP == 0) {
+          past.own   = (past.own << 8) | byte[j];
+          past.above = (past.above << 8) | bu[j];
+        }
+        o.w[j >> 2] |= byte[j] << (8 * (j & 3));
+      }
+      if constexpr (BPP != 0) {
+#pragma unroll
+        for (int j = 0; j < BPP; j++) {
+          past.own[j]   = byte[16 - BPP + j];
+          past.above[j] = bu[16 - BPP + j];
+        }
+      }
+      *(PngPiece16 *)(tile + lane * PNG_PITCH + 16u * k) = o;
+    }
+    group_sync();
+    const bool inner = t0 + 1u >= nrow && t0 + PNG_WIN <= rb;     // every row's window lies inside the row
+#pragma unroll
+    for (uint32_t u = 0; u < PNG_NI; u++) {
+      const uint32_t q = u * PNG_RPI + sub, x = t0 + 16u * piece - q;
+      if (q < nrow) {
+        const PngPiece16 v = *(const PngPiece16 *)(tile + q * PNG_PITCH + 16u * piece);
+        uint8_t *d = ob + (uint64_t)(r0 + q) * rb + (int64_t)(int32_t)x;
+        if (inner || (x < rb && rb - x >= 16u)) {
+          PngPiece o = {{v.w[0], v.w[1], v.w[2], v.w[3]}};
+          *(PngPiece *)d = o;
+        }
+      }
+    }
+    if (!inner && lane < nrow) {
+      // The bytes of pieces that straddle an end of their row: at most the first 15 and the last 15 bytes of a row;
+      // here every lane looks after its own row.
+      const uint32_t ws = t0 - lane;                                 // x of the tile row's first byte
+      for (uint32_t e = 0; e < 30; e++) {
+        const uint32_t x = e < 15 ? e : rb - 1u - (e - 15u), off = x - ws;
+        if (x < rb && off < PNG_WIN) {
+          const uint32_t ps = ws + (off & ~15u);                     // x of the piece's first byte
+          if (!(ps < rb && rb - ps >= 16u)) ob[(uint64_t)(r0 + lane) * rb + x] = tile[lane * PNG_PITCH + off];
+        }
+      }
+    }
+    group_sync();
+    if (!more) break;
+    // The next band's lane 0 reads this band's last row back from memory.  Writer and reader are this wavefront:
+    // its stores have to be complete, no cache has to be written back or invalidated.
+    if (!more_here) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    r0 = r0n;
+    t0 = t0n;
+  }
+#undef PNG_FETCH
+  return bad;
+}
+
+__device__ __forceinline__ void png_unfilter_one(uint8_t *tile, uint64_t i, uint32_t lane, const uint8_t *in,
+                                                 const uint64_t *in_off, const uint32_t *in_len, const int32_t *in_status,
+                                                 uint8_t *out, const uint64_t *out_off, const InflPngGeom *geom,
+                                                 int32_t *status) {
+  const InflPngGeom g = geom[i];
+  const uint64_t i0 = in_off[i], i1 = in_off[i + 1], o0 = out_off[i], o1 = out_off[i + 1];
+  uint64_t have = i1 >= i0 ? i1 - i0 : 0;
+  if (in_len && in_len[i] < have) have = in_len[i];
+  const uint32_t rows = g.rows, rb = g.rowbytes;
+  const uint64_t need_in = (uint64_t)rows * ((uint64_t)rb + 1u), need_out = (uint64_t)rows * rb;
+  const bool fits = g.bpp >= 1 && g.bpp <= 8 && need_in < 0xfffffc00ull && need_in <= have && o1 >= o0 &&
+                    need_out <= o1 - o0 && !(in_status && in_status[i] != 0);
+  if (!fits) {
+    if (lane == 0) status[i] = -1;
+    return;
+  }
+  const uint8_t *ib = in + i0;
+  uint8_t       *ob = out + o0;
+  bool bad = false;
+  if (rows == 0) {                                   // nothing to rebuild
+  } else if (rb == 0) {                              // filter bytes only
+    for (uint32_t r = lane; r < rows; r += 64) bad |= ib[r] > 4;
+  } else {
+    switch (g.bpp) {                                 // the pixel sizes a PNG can have, each with its own code
+      case 1: bad = png_unfilter_image<1>(tile, ib, (uint32_t)need_in, ob, rows, rb, 1, lane); break;
+      case 2: bad = png_unfilter_image<2>(tile, ib, (uint32_t)need_in, ob, rows, rb, 2, lane); break;
+      case 3: bad = png_unfilter_image<3>(tile, ib, (uint32_t)need_in, ob, rows, rb, 3, lane); break;
+      case 4: bad = png_unfilter_image<4>(tile, ib, (uint32_t)need_in, ob, rows, rb, 4, lane); break;
+      case 6: bad = png_unfilter_image<6>(tile, ib, (uint32_t)need_in, ob, rows, rb, 6, lane); break;
+      case 8: bad = png_unfilter_image<8>(tile, ib, (uint32_t)need_in, ob, rows, rb, 8, lane); break;
+      default: bad = png_unfilter_image<0>(tile, ib, (uint32_t)need_in, ob, rows, rb, g.bpp, lane); break;
+    }
+  }
+  const bool any_bad = __ballot(bad) != 0;
+  if (lane == 0) status[i] = any_bad ? -1 : 0;
+}
+
+// One wavefront per workgroup; a workgroup takes images blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher sizes the
+// grid to what the device holds at once: thousands of one-wavefront workgroups that live a few tens of microseconds
+// each are started more slowly than they finish).
+__global__ __launch_bounds__(64) void infl_png_unfilter_kernel(const uint8_t *in, const uint64_t *in_off,
+                                                                const uint32_t *in_len, const int32_t *in_status,
+                                                                uint8_t *out, const uint64_t *out_off,
+                                                                const InflPngGeom *geom, uint64_t n, int32_t *status) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[65 * PNG_PITCH];
+  for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    png_unfilter_one(tile, i, threadIdx.x, in, in_off, in_len, in_status, out, out_off, geom, status);
+    group_sync();
+  }
+}
+
 }  // namespace defl
 
 // variant 0: reference-geometry tables only (one launch).
@@ -2181,6 +2488,27 @@ extern "C" int infl_launch_resume(const void *src, uint32_t srclen, void *dst, u
                                   InflResume *state, void *stream) {
   hipLaunchKernelGGL((defl::infl_resume_kernel<64>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)src,
                      srclen, (uint8_t *)dst, cap, zlib, state);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int infl_launch_png_unfilter(const void *in, const uint64_t *in_off, const uint32_t *in_len,
+                                        const int32_t *in_status, void *out, const uint64_t *out_off,
+                                        const InflPngGeom *geom, uint64_t n, int32_t *status, void *stream) {
+  if (n == 0) return 0;
+  // as many workgroups as fit on the device at once (9 tiles in a compute unit's 160 KiB of LDS)
+  static std::atomic<unsigned> resident[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  unsigned slots = resident[dev].load(std::memory_order_relaxed);
+  if (!slots) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return -1;
+    slots = (unsigned)cus * 9u;
+    resident[dev].store(slots, std::memory_order_relaxed);
+  }
+  const unsigned grid = n < slots ? (unsigned)n : slots;
+  hipLaunchKernelGGL(defl::infl_png_unfilter_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream,
+                     (const uint8_t *)in, in_off, in_len, in_status, (uint8_t *)out, out_off, geom, n, status);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

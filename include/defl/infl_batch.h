@@ -109,6 +109,33 @@ infl_batch_checked(const void *src, const uint64_t *src_off,
                    int32_t *status, uint32_t *outlen, int32_t *detail);
 
 /*
+ * PNG un-filter on the GPU: the step that follows inflate when the streams are PNG image data
+ * ("undo filters", which the reference leaves to its caller: README.md:150-152; it holds no code for
+ * it, the rule is the PNG specification's, section 9).  Image i is geom[i].rows scanlines of one
+ * filter-type byte (0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth) and geom[i].rowbytes filtered bytes at
+ * dev_in + dev_in_off[i]; its rows * rowbytes rebuilt bytes go to dev_out + dev_out_off[i].  bpp =
+ * bytes per complete pixel, rounded up to 1 (1, 2, 3, 4, 6 or 8 in a PNG; 1..8 accepted).
+ * To run it behind infl_batch_dev() pass that call's dev_dst / dev_dst_off as dev_in / dev_in_off,
+ * its dev_outlen as dev_in_len (bytes present; NULL = all of dev_in_off[i+1] - dev_in_off[i]) and
+ * its dev_status as dev_in_status (NULL = none): an image whose stream failed fails here too.
+ * dev_status[i] = 0, or -1 (stream failed, fewer than rows * (rowbytes + 1) bytes present, no room
+ * for the output, bpp out of range, or a filter type above 4; the image's output is then
+ * unspecified).  dev_out must not overlap dev_in.  The call enqueues on hip_stream and returns.
+ */
+#ifndef INFL_PNG_GEOM_DEFINED
+#define INFL_PNG_GEOM_DEFINED
+typedef struct InflPngGeom {
+  uint32_t rows, rowbytes, bpp, reserved;
+} InflPngGeom;
+#endif
+UNZ_EXPORT int
+infl_png_unfilter_dev(const void *dev_in, const uint64_t *dev_in_off,
+                      const uint32_t *dev_in_len, const int32_t *dev_in_status,
+                      void *dev_out, const uint64_t *dev_out_off,
+                      const InflPngGeom *dev_geom, size_t n,
+                      int32_t *dev_status, void *hip_stream);
+
+/*
  * infl_batch() for callers that cannot allocate: tight serving loops, harnesses that forbid
  * hipMalloc, code that runs while a HIP graph is being captured elsewhere in the process.  It has
  * no counterpart in the reference.  Same arguments and results as infl_batch(), but the device

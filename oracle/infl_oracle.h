@@ -50,6 +50,10 @@ void oracle_set_header_hook(void (*hook)(const uint8_t *lens, unsigned hlit, uns
 int oracle_table_build(uint32_t *table, unsigned *used_out, const uint8_t *lens,
                        unsigned nsyms, unsigned tablebits, unsigned cap, int litlen);
 
+/* PNG un-filter (png_unfilter.c): rows x (1 + rowbytes) filtered bytes -> rows x rowbytes bytes.
+   0, or -1 when a row names a filter type above 4. */
+int oracle_png_unfilter(const uint8_t *in, uint8_t *out, uint32_t rows, uint32_t rowbytes, uint32_t bpp);
+
 #ifdef __cplusplus
 }
 #endif

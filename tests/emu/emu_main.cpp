@@ -22,7 +22,7 @@ struct Group {
 };
 int g_slots[2][1024];   // ds_bpermute exchange buffers, one slot per thread of the workgroup (read within the wavefront)
 pthread_barrier_t *g_block_bar = nullptr;   // __syncthreads of the workgroup that is running
-thread_local dim3     t_threadIdx, t_blockIdx;
+thread_local dim3     t_threadIdx, t_blockIdx, t_gridDim;
 thread_local Group   *t_group = nullptr;
 thread_local int      t_lane  = 0;
 thread_local unsigned t_ballots = 0, t_permutes = 0;
@@ -62,6 +62,7 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
       th.emplace_back([&, t] {
         t_threadIdx = dim3(t);
         t_blockIdx  = dim3(b);
+        t_gridDim   = dim3(grid);
         t_lane      = (int)t;
         t_group     = &groups[t / T];
         t_ballots = t_permutes = 0;
@@ -145,9 +146,48 @@ static int main_resume(int argc, char **argv) {
   return 0;
 }
 
+// emu_run <in.bin> <out.bin> png 0 0: the PNG un-filter kernel.
+//   in : u64 n, u64 in_off[n+1], u64 out_off[n+1], u32 geom[4n], u32 in_len[n], i32 in_status[n], filtered bytes
+//   out: i32 status[n], rebuilt bytes
+// Every image gets exact-size buffers of its own, so that AddressSanitizer sees any access outside them.
+static int main_png(char **argv) {
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, f) != 1) return 2;
+  std::vector<uint64_t> io(n + 1), oo(n + 1);
+  std::vector<InflPngGeom> geom(n);
+  std::vector<uint32_t> in_len(n);
+  std::vector<int32_t>  in_status(n), status(n, -99);
+  if (fread(io.data(), 8, n + 1, f) != n + 1 || fread(oo.data(), 8, n + 1, f) != n + 1 ||
+      fread(geom.data(), 16, n, f) != n || fread(in_len.data(), 4, n, f) != n || fread(in_status.data(), 4, n, f) != n)
+    return 2;
+  std::vector<uint8_t> in(io[n] ? io[n] : 1), out(oo[n] ? oo[n] : 1, 0xee);
+  if (io[n] && fread(in.data(), 1, io[n], f) != io[n]) return 2;
+  fclose(f);
+  emu::g_lanes_per_group = 64;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint64_t il = io[i + 1] - io[i], ol = oo[i + 1] - oo[i];
+    uint8_t *bi = (uint8_t *)malloc(il ? il : 1), *bo = (uint8_t *)malloc(ol ? ol : 1);
+    memcpy(bi, in.data() + io[i], il);
+    memset(bo, 0xee, ol);
+    const uint64_t one_in[2] = {0, il}, one_out[2] = {0, ol};
+    if (infl_launch_png_unfilter(bi, one_in, &in_len[i], &in_status[i], bo, one_out, &geom[i], 1, &status[i], nullptr) != 0) return 3;
+    memcpy(out.data() + oo[i], bo, ol);
+    free(bi);
+    free(bo);
+  }
+  f = fopen(argv[2], "wb");
+  fwrite(status.data(), 4, n, f);
+  fwrite(out.data(), 1, oo[n], f);
+  fclose(f);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 6) return 2;
   if (!strcmp(argv[3], "resume")) return main_resume(argc, argv);
+  if (!strcmp(argv[3], "png")) return main_png(argv);
   FILE *f = fopen(argv[1], "rb");
   if (!f) return 2;
   uint64_t n = 0;

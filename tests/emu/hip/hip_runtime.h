@@ -17,7 +17,10 @@ struct uint4 { uint32_t x, y, z, w; };
 typedef void *hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
+enum { hipDeviceAttributeMultiprocessorCount = 1 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 1; return hipSuccess; }   // a one-CU device: small grids
 
 #define __device__
 #define __constant__ static
@@ -29,7 +32,7 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 
 namespace emu {
 struct Group;
-extern thread_local dim3   t_threadIdx, t_blockIdx;
+extern thread_local dim3   t_threadIdx, t_blockIdx, t_gridDim;
 extern thread_local Group *t_group;
 extern thread_local int    t_lane;
 void     group_barrier();
@@ -41,6 +44,7 @@ void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 
 #define threadIdx emu::t_threadIdx
 #define blockIdx emu::t_blockIdx
+#define gridDim emu::t_gridDim
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
   emu::launch((grid).x, (block).x, [=] { kern(__VA_ARGS__); })
@@ -59,14 +63,31 @@ static inline uint32_t __builtin_amdgcn_udot4(uint32_t a, uint32_t b, uint32_t c
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
 }
-// DPP controls used by the kernel: row_shr:n (0x110 + n) and the two row broadcasts; lanes whose
-// source lies outside their row of 16, or whose row is masked off, get `old`.
+// v_sad_u8 / v_sad_u16: c + the sum of absolute differences of the four bytes / two halves of a and b
+static inline uint32_t __builtin_amdgcn_sad_u8(uint32_t a, uint32_t b, uint32_t c) {
+  for (int k = 0; k < 4; k++) {
+    const int x = (a >> (8 * k)) & 0xff, y = (b >> (8 * k)) & 0xff;
+    c += (uint32_t)(x > y ? x - y : y - x);
+  }
+  return c;
+}
+static inline uint32_t __builtin_amdgcn_sad_u16(uint32_t a, uint32_t b, uint32_t c) {
+  for (int k = 0; k < 2; k++) {
+    const int x = (a >> (16 * k)) & 0xffff, y = (b >> (16 * k)) & 0xffff;
+    c += (uint32_t)(x > y ? x - y : y - x);
+  }
+  return c;
+}
+// DPP controls used by the kernels: row_shr:n (0x110 + n), the two row broadcasts and wave_shr:1 (0x138); lanes
+// whose source lies outside their row of 16 (outside the wavefront for wave_shr), or whose row is masked off, get `old`.
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int, bool) {
   const int lane = emu::t_lane, row = lane >> 4;
   int from = -1;
   if (ctrl >= 0x111 && ctrl <= 0x11f) {
     const int n = ctrl - 0x110;
     if ((lane & 15) >= n) from = lane - n;
+  } else if (ctrl == 0x138) {                      // wave_shr:1
+    if (lane & 63) from = lane - 1;
   } else if (ctrl == 0x142) {                      // row_bcast:15
     if (row >= 1) from = row * 16 - 1;
   } else if (ctrl == 0x143) {                      // row_bcast:31

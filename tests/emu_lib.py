@@ -61,3 +61,32 @@ def run_resume(src, src_off, dst_off, flags=0, chunk=1, timeout=900):
     outlen = np.frombuffer(raw, dtype=np.uint32, count=n, offset=4 * n)
     dst = np.frombuffer(raw, dtype=np.uint8, offset=8 * n)
     return dst, status, outlen
+
+
+def run_png(filtered, geom, in_len=None, in_status=None, timeout=900):
+    """The PNG un-filter kernel on a list of filtered images; geom = [(rows, rowbytes, bpp)].
+    -> (list of rebuilt images, status)"""
+    build()
+    n = len(filtered)
+    io = np.zeros(n + 1, dtype=np.uint64)
+    oo = np.zeros(n + 1, dtype=np.uint64)
+    io[1:] = np.cumsum([len(f) for f in filtered], dtype=np.uint64)
+    oo[1:] = np.cumsum([r * rb for r, rb, _ in geom], dtype=np.uint64)
+    g = np.zeros((n, 4), dtype=np.uint32)
+    for i, (rows, rowbytes, bpp) in enumerate(geom):
+        g[i, :3] = rows, rowbytes, bpp
+    in_len = np.array([len(f) for f in filtered] if in_len is None else in_len, dtype=np.uint32)
+    in_status = np.zeros(n, dtype=np.int32) if in_status is None else np.array(in_status, dtype=np.int32)
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.uint64(n).tobytes() + io.tobytes() + oo.tobytes() + g.tobytes() + in_len.tobytes() +
+                    in_status.tobytes() + b"".join(filtered))
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+        p = subprocess.run([EXE, fin, fout, "png", "0", "0", "0"], env=env, timeout=timeout, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("emu_run png failed (%d): %s" % (p.returncode, p.stderr[-3000:]))
+        raw = open(fout, "rb").read()
+    status = np.frombuffer(raw, dtype=np.int32, count=n, offset=0)
+    out = raw[4 * n:]
+    return [out[int(oo[i]):int(oo[i + 1])] for i in range(n)], status

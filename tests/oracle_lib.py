@@ -32,6 +32,15 @@ class Oracle:
         lib.oracle_table_build.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.c_void_p, C.c_uint,
                                            C.c_uint, C.c_uint, C.c_int]
 
+    def png_unfilter(self, data: bytes, rows: int, rowbytes: int, bpp: int):
+        """-> (rc, unfiltered bytes)"""
+        self.lib.oracle_png_unfilter.restype = C.c_int
+        self.lib.oracle_png_unfilter.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        ibuf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\0")
+        obuf = (C.c_uint8 * max(1, rows * rowbytes))()
+        rc = self.lib.oracle_png_unfilter(ibuf, obuf, rows, rowbytes, bpp)
+        return rc, bytes(obuf[: rows * rowbytes])
+
     def infl(self, src: bytes, dstlen: int, flags: int = 0):
         """-> (rc, dstpos, out bytes[0:dstpos], detail)"""
         src = bytes(src)
@@ -72,7 +81,7 @@ _cached = None
 def load() -> Oracle:
     global _cached
     if _cached is None:
-        src_m = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("infl_oracle.c", "infl_oracle.h"))
+        src_m = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("infl_oracle.c", "infl_oracle.h", "png_unfilter.c"))
         if not os.path.exists(SO) or os.path.getmtime(SO) < src_m:
             build()
         _cached = Oracle(C.CDLL(SO))

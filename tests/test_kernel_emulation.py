@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import workloads as wl
-from tests import emu_lib
+from tests import emu_lib, oracle_lib
 from tests.deflate_builder import header_cases
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -279,3 +279,34 @@ def test_emulated_integrity_passes():
     assert list(status[k:]) == [-1] * 7
     assert list(detail[k:k + 2]) == [5, 5] and detail[k + 2] == 2 and detail[k + 3] == 2     # mismatches; trailer / header cut
     assert detail[k + 4] == 1 and detail[k + 5] == 1 and detail[k + 6] == 2                   # not gzip (twice); nothing there
+
+
+def test_emulated_png_unfilter():
+    """The PNG un-filter kernel under AddressSanitizer with exact-size buffers per image: several bands, rows
+    shorter and longer than the 16-byte pieces and the 256-byte windows, every bpp, empty images, failures."""
+    oracle = oracle_lib.load()
+    rng = np.random.default_rng(5)
+    filtered, geom, want = [], [], []
+    for i, (w, h, bpp) in enumerate([(20, 10, 4), (1, 1, 1), (3, 1, 8), (5, 2, 3), (15, 66, 1), (16, 64, 1), (17, 3, 2),
+                                     (70, 5, 4), (300, 2, 1), (129, 70, 2), (9, 130, 6), (40, 65, 8), (272, 3, 1)]):
+        pixels, f, _ = wl.png_filtered(i, w, h, bpp)
+        filtered.append(f); geom.append((h, w * bpp, bpp)); want.append(pixels)
+    for bpp in (5, 7):
+        rows, rowbytes = 9, 5 * bpp
+        d = rng.integers(0, 256, size=(rows, rowbytes + 1), dtype=np.uint8)
+        d[:, 0] = rng.integers(0, 5, size=rows)
+        filtered.append(d.tobytes()); geom.append((rows, rowbytes, bpp)); want.append(oracle.png_unfilter(d.tobytes(), rows, rowbytes, bpp)[1])
+    filtered.append(b""); geom.append((0, 64, 4)); want.append(b"")
+    filtered.append(bytes([0, 1, 2, 3, 4])); geom.append((5, 0, 1)); want.append(b"")
+    for f, g, w_ in zip(filtered, geom, want):
+        assert oracle.png_unfilter(f, *g) == (0, w_)
+    out, st = emu_lib.run_png(filtered, geom)
+    for i, w_ in enumerate(want):
+        assert st[i] == 0 and out[i] == w_, (i, geom[i])
+    # failures: a filter type above 4 (in the second band), too little input, a failed stream, bpp out of range
+    pixels, good, _ = wl.png_filtered(3, 8, 70, 4)
+    late = bytearray(good); late[69 * 33] = 9
+    out, st = emu_lib.run_png([good, bytes(late), good, good, good, good], [(70, 32, 4)] * 4 + [(70, 32, 0), (70, 32, 9)],
+                              in_len=[len(good), len(good), len(good) - 1, len(good), len(good), len(good)],
+                              in_status=[0, 0, 0, -1, 0, 0])
+    assert list(st) == [0, -1, -1, -1, -1, -1] and out[0] == pixels

@@ -25,6 +25,91 @@ __global__ __launch_bounds__(64) void k_valu(uint32_t *out, int iters, uint64_t 
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// One dependent chain per wave, 64 links per iteration: cycles per link for one resident wave per SIMD.
+// KIND 0 v_add_u32; 1 v_sad_u8; 2 v_cmp + v_cndmask through vcc; 3 v_mov_dpp wave_shr:1 + v_add; 4 v_mov_dpp row_shr:1 + v_add;
+// 5 v_and_or_b32; 6 ds_bpermute + v_add; 7 v_add_u32 with SDWA byte select
+template <int KIND>
+__global__ __launch_bounds__(64) void k_chain(uint32_t *out, int iters, uint64_t *cyc) {
+  uint32_t a = threadIdx.x * 17 + out[0], b = threadIdx.x + 3, c = 0;
+  uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      if (KIND == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+      if (KIND == 1) asm volatile("v_sad_u8 %0, %0, %1, 0" : "+v"(a) : "v"(b));
+      if (KIND == 2) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_add_u32 %0, %0, %1" : "+v"(a) : "v"(b) : "vcc");
+      if (KIND == 3) asm volatile("s_nop 1\n\tv_mov_b32_dpp %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32 %0, %1, %2" : "+v"(a), "+v"(c) : "v"(b));
+      if (KIND == 4) asm volatile("s_nop 1\n\tv_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32 %0, %1, %2" : "+v"(a), "+v"(c) : "v"(b));
+      if (KIND == 5) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
+      if (KIND == 6) { a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x + 63u) & 63u) << 2), (int)a) + b; }
+      if (KIND == 7) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "+v"(a) : "v"(b));
+    }
+  }
+  uint64_t t1 = __builtin_amdgcn_s_memtime();
+  if (a + c == 0x12345678u) out[1] = a;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+// Issue cost: 16 independent chains per wave, 4 waves per SIMD; cycles of SIMD time per instruction.  KIND as in k_chain.
+template <int KIND>
+__global__ __launch_bounds__(64) void k_rate(uint32_t *out, int iters, uint64_t *cyc) {
+  uint32_t a[16], b = threadIdx.x + 3, c[16];
+  for (int i = 0; i < 16; i++) a[i] = threadIdx.x * 17 + i + out[0], c[i] = 0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (KIND == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        if (KIND == 1) asm volatile("v_sad_u8 %0, %0, %1, 0" : "+v"(a[i]) : "v"(b));
+        if (KIND == 2) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+        if (KIND == 3) asm volatile("v_mov_b32_dpp %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]), "+v"(c[i]));
+        if (KIND == 4) asm volatile("v_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]), "+v"(c[i]));
+        if (KIND == 5) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+        if (KIND == 6) asm volatile("v_sad_u16 %0, %0, %1, 0" : "+v"(a[i]) : "v"(b));
+        if (KIND == 7) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "+v"(a[i]) : "v"(b));
+        if (KIND == 8) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a[i]));
+        if (KIND == 9) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        if (KIND == 10) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+        if (KIND == 11) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(a[i]) : "v"(b));
+      }
+    }
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < 16; i++) s += a[i] + c[i];
+  if (s == 0x12345678u) out[1] = s;
+}
+
+// The PNG un-filter step sequence (bpp 4) on registers only: cycles per step at 1, 2 and 3 waves per SIMD.
+__global__ __launch_bounds__(64) void k_png_steps(uint32_t *out, int iters) {
+  const uint32_t lane = threadIdx.x, ft = (lane + blockIdx.x) % 5u;
+  const uint32_t m_sub = ft == 1 ? 0xffu : 0u, m_up = ft == 2 ? 0xffu : 0u, m_avg = ft == 3 ? 0xffu : 0u, m_paeth = ft == 4 ? 0xffu : 0u;
+  uint32_t own[4] = {0, 0, 0, 0}, above[4] = {0, 0, 0, 0}, prev = 0, acc = 0;
+  uint32_t cur[4] = {lane * 0x01010101u + out[0], lane * 77u, lane * 0x9e3779b9u, lane + 5u}, upc[4] = {1, 2, 3, 4};
+  for (int it = 0; it < iters; it++) {
+    uint32_t byte[16], bu[16], o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t v = (cur[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      bu[j] = (uint32_t)__builtin_amdgcn_update_dpp((int)((upc[j >> 2] >> (8 * (j & 3))) & 0xffu), (int)prev, 0x138, 0xf, 0xf, false);
+      const uint32_t a = j >= 4 ? byte[j >= 4 ? j - 4 : 0] : own[j < 4 ? j : 0];
+      const uint32_t c = j >= 4 ? bu[j >= 4 ? j - 4 : 0] : above[j < 4 ? j : 0];
+      const uint32_t b = bu[j], ab = a + b;
+      const uint32_t pa = __builtin_amdgcn_sad_u8(b, c, 0), pb = __builtin_amdgcn_sad_u8(a, c, 0), pc = __builtin_amdgcn_sad_u16(ab, c << 1, 0);
+      const uint32_t paeth = pa <= (pb < pc ? pb : pc) ? a : pb <= pc ? b : c;
+      const uint32_t pred = (a & m_sub) | (b & m_up) | ((ab >> 1) & m_avg) | (paeth & m_paeth);
+      byte[j] = (v + pred) & 0xffu;
+      prev = byte[j];
+      o[j >> 2] |= byte[j] << (8 * (j & 3));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) own[j] = byte[12 + j], above[j] = bu[12 + j];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { acc ^= o[w]; cur[w] = cur[w] * 1664525u + 1013904223u; }
+  }
+  if (acc == 0x12345678u) out[1] = acc;
+}
+
 // MODE 0 aligned b32, 1 unaligned b32, 2 aligned b64, 3 unaligned b64, 4 aligned b128, 5 unaligned b128 (random addresses)
 template <int MODE>
 __global__ __launch_bounds__(64) void k_lds_read(uint32_t *out, int iters, uint32_t seed) {
@@ -115,6 +200,37 @@ int main() {
     double instr = (double)iters * 48.0 * grid;           // 3 VALU per element and iteration (shift, add, xor)
     printf("valu waves/SIMD %d: %.3f ms, wave cycles %llu (%.2f GHz), %.3f VALU instr per ns per SIMD = %.3f per cycle at 2.4 GHz\n",
            w, ms, (unsigned long long)c, c / (ms * 1e6), instr / (ms * 1e6) / (CUS * 4), instr / (ms * 1e6) / (CUS * 4) / 2.4);
+  }
+  {
+    const char *cn[] = {"v_add_u32", "v_sad_u8", "v_cmp+v_cndmask+v_add", "s_nop 1+dpp wave_shr:1+v_add", "s_nop 1+dpp row_shr:1+v_add", "v_and_or_b32",
+                        "ds_bpermute+v_add", "v_add_u32 sdwa"};
+    for (int w : {1, 2}) {
+      const int iters = 2000, grid = CUS * 4 * w;
+      float ms[8];
+      uint64_t cy[8];
+#define CHAIN(K) ms[K] = timeit([&] { hipLaunchKernelGGL(k_chain<K>, dim3(grid), dim3(64), 0, 0, out, iters, cyc); }); CK(hipMemcpy(&cy[K], cyc, 8, hipMemcpyDeviceToHost));
+      CHAIN(0) CHAIN(1) CHAIN(2) CHAIN(3) CHAIN(4) CHAIN(5) CHAIN(6) CHAIN(7)
+      for (int k = 0; k < 8; k++)
+        printf("dependent chain, %d wave(s)/SIMD, %-30s: %.3f ms = %.1f cycles per link at 2.4 GHz (s_memtime: %.1f ticks per link)\n", w, cn[k], ms[k],
+               ms[k] * 2.4e6 / (iters * 64.0), (double)cy[k] / (iters * 64.0));
+    }
+  }
+  {
+    const char *cn[] = {"v_add_u32", "v_sad_u8", "v_cmp+v_cndmask (2 instr)", "v_mov_dpp wave_shr:1", "v_mov_dpp row_shr:1", "v_and_or_b32", "v_sad_u16",
+                        "v_add_u32 sdwa", "v_bfe_u32", "v_min_u32", "v_or3_b32", "v_lshl_or_b32"};
+    const int iters = 2000, grid = CUS * 16;
+    float ms[12];
+#define RATE(K) ms[K] = timeit([&] { hipLaunchKernelGGL(k_rate<K>, dim3(grid), dim3(64), 0, 0, out, iters, cyc); });
+    RATE(0) RATE(1) RATE(2) RATE(3) RATE(4) RATE(5) RATE(6) RATE(7) RATE(8) RATE(9) RATE(10) RATE(11)
+    for (int k = 0; k < 12; k++)
+      printf("issue cost, 4 waves/SIMD, 16 chains, %-26s: %.3f ms = %.2f SIMD cycles per asm statement at 2.4 GHz\n", cn[k], ms[k],
+             ms[k] * 2.4e6 / (iters * 64.0 * 4));
+  }
+  for (int w : {1, 2, 3, 4}) {
+    const int iters = 4000, g2 = CUS * 4 * w;
+    float ms = timeit([&] { hipLaunchKernelGGL(k_png_steps, dim3(g2), dim3(64), 0, 0, out, iters); });
+    printf("png steps on registers, %d wave(s)/SIMD: %.3f ms = %.1f cycles per step and wave, %.1f SIMD cycles per step at 2.4 GHz\n", w, ms,
+           ms * 2.4e6 / (iters * 16.0), ms * 2.4e6 / (iters * 16.0) / w);
   }
   const int grid = CUS * 16, iters = 4000;
   const char *rn[] = {"read b32 aligned", "read b32 unaligned", "read b64 aligned", "read b64 unaligned", "read b128 aligned", "read b128 unaligned"};

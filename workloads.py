@@ -109,6 +109,46 @@ def png_like(i: int, width=128, height=128) -> bytes:
     return rows.tobytes()
 
 
+def png_filter(pixels: np.ndarray, bpp: int, types) -> bytes:
+    """The encoder's side of PNG filtering (PNG specification, section 9): pixels = (rows, rowbytes) uint8,
+    types[r] = filter type of scanline r (0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth).  -> rows of 1 + rowbytes bytes."""
+    rows, rowbytes = pixels.shape
+    cur = pixels.astype(np.int32)
+    a = np.zeros_like(cur)
+    a[:, bpp:] = cur[:, :rowbytes - bpp] if rowbytes > bpp else 0
+    b = np.zeros_like(cur)
+    b[1:] = cur[:-1]
+    c = np.zeros_like(cur)
+    c[1:, bpp:] = cur[:-1, :rowbytes - bpp] if rowbytes > bpp else 0
+    p = a + b - c
+    pa, pb, pc = np.abs(p - a), np.abs(p - b), np.abs(p - c)
+    paeth = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+    pred = [np.zeros_like(cur), a, b, (a + b) >> 1, paeth]
+    out = np.zeros((rows, 1 + rowbytes), dtype=np.uint8)
+    for r in range(rows):
+        t = int(types[r])
+        out[r, 0] = t
+        out[r, 1:] = ((cur[r] - pred[t][r]) & 0xFF).astype(np.uint8)
+    return out.tobytes()
+
+
+def png_filtered(i: int, width=128, height=128, bpp=4, types=None):
+    """png_like()'s picture at bpp bytes per pixel with real filter types: by default the five types in a
+    seeded shuffle, so that every type meets every type above it.  -> (pixel bytes, filtered bytes, types)"""
+    rng = np.random.default_rng(stream_seed(i) ^ 0xF117E4)
+    y, x = np.mgrid[0:height, 0:width]
+    img = np.empty((height, width, bpp), dtype=np.uint8)
+    for ch in range(bpp):
+        img[..., ch] = ((x * (ch + 1) + y * (bpp - ch)) * 255 // max(1, (width + height) * bpp)).astype(np.uint8)
+    img ^= rng.integers(0, 8, size=img.shape, dtype=np.uint8)
+    if height and width:
+        img[rng.integers(0, height), :, :] = rng.integers(0, 256, size=(width, bpp), dtype=np.uint8)   # one noisy line
+    pixels = img.reshape(height, width * bpp)
+    if types is None:
+        types = rng.integers(0, 5, size=height)
+    return pixels.tobytes(), png_filter(pixels, bpp, types), [int(t) for t in types]
+
+
 def idat_pieces(i: int, comp: bytes) -> list:
     """Cut a zlib stream into IDAT-like pieces: 50 % exactly 8192 B, 25 % 1..64 B, 25 % 64..4096 B."""
     rng = np.random.default_rng(stream_seed(i) ^ 0x1DA7C)
