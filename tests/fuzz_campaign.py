@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzz of the GPU engine against the CPU oracle, larger than what the test suite runs
-(diagnostic: `python tools/fuzz_campaign.py [first seed] [seeds] [seconds]` on a GPU box).  Streams that
+(diagnostic: `python tests/fuzz_campaign.py [first seed] [seeds] [seconds]` on a GPU box).  Streams that
 stress the parallel decoder's special paths (rounds cut short, serial stretches, failing streams
 reported by the parallel pass): text with runs, near fixed-length codes, fixed-Huffman blocks, flush
 points; mutated, truncated, with too little output space.  Both entry points are compared, bit for bit."""

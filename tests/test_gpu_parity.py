@@ -191,8 +191,8 @@ def test_dynamic_header_edge_cases(engine, oracle):
 
 
 def test_text_batch_roundtrip_full_size(engine, oracle):
-    """Config-2 shaped batch (64 KiB text streams, zlib level 6): compare against the raw
-    text itself, and a sample against the oracle."""
+    """Config-2 shaped batch (64 KiB text streams, zlib level 6): every stream against the raw text it was
+    made from, and a sample (status, output position, bytes) against the oracle."""
     n = 512
     raws = [wl.text_stream(i) for i in range(n)]
     streams = [wl.deflate(r) for r in raws]
@@ -205,6 +205,9 @@ def test_text_batch_roundtrip_full_size(engine, oracle):
         b.free()
     assert (status == 0).all() and (outlen == 65536).all()
     assert dst[:n * 65536].tobytes() == b"".join(raws)
+    for i in (0, 1, 77, 255, n - 1):
+        rc, pos, out, _ = oracle.infl(streams[i], 65536, 1)
+        assert (rc, pos) == (int(status[i]), int(outlen[i])) and out[:pos] == dst[i * 65536:i * 65536 + pos].tobytes()
 
 
 def test_host_batch_and_many(engine, oracle):

@@ -20,4 +20,4 @@ pass c TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE &&
 pass d FETCH_SIZE &&
 pass e WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 python3 tools/pmc_summary.py gpurun_out/${tag}_a gpurun_out/${tag}_b gpurun_out/${tag}_c gpurun_out/${tag}_d gpurun_out/${tag}_e > gpurun_out/${tag}_summary.csv
-grep -E "Li3E|png" gpurun_out/${tag}_summary.csv
+grep -E "CompactFmt, 3|png" gpurun_out/${tag}_summary.csv || true
