@@ -369,6 +369,18 @@ __device__ __forceinline__ uint32_t rd_real(const FastReader<T> &r) {
   return left <= 0 ? 0u : left < (int64_t)r.n ? (uint32_t)left : r.n;
 }
 __device__ __forceinline__ const uint8_t *rd_end(const Reader &r) { return r.end; }
+// Input bits between the reader's position and the end of the input (what the reference's reservoir could
+// still be filled with), capped at 2^30.  After rd_fill, "rd_real(r) < k" is "rd_left(r) < k" for k <= 32:
+// a loop that counts what it drops needs the 64-bit arithmetic once, not at every test.
+__device__ __forceinline__ int32_t rd_left(const Reader &r) {
+  const uint64_t left = (uint64_t)r.n + 8u * (uint64_t)(r.end - r.p);
+  return left < (1u << 30) ? (int32_t)left : (int32_t)(1u << 30);
+}
+template <int T>
+__device__ __forceinline__ int32_t rd_left(const FastReader<T> &r) {
+  const int64_t left = (int64_t)r.ilen * 8 - ((int64_t)r.ipos * 8 - (int64_t)r.n);
+  return left <= 0 ? 0 : left < (int64_t)(1 << 30) ? (int32_t)left : (int32_t)(1 << 30);
+}
 
 template <class F>
 __device__ __forceinline__ uint32_t tab_lookup(const typename F::entry_t *tab, int mainbits,
@@ -434,6 +446,139 @@ __device__ __forceinline__ void coop_match(uint8_t *dst, uint32_t pos, uint32_t 
 // ---------------------------------------------------------------------------
 enum : int { BUILD_OK = 0, BUILD_REJECT = 1, BUILD_NOFIT = 2 };
 
+#ifdef DEFL_PAR_PROFILE
+__device__ unsigned long long g_par_prof[32];   // diagnostic builds: cycle and event counters of the parallel pass
+#endif
+#ifdef DEFL_PAR_PROFILE_SETUP                    // split of the block set-up time (takes the slots of the scan histogram)
+#define SETUP_MARK(k) { if (T == 64) { const uint64_t t_ = __builtin_readcyclecounter(); if (lig == 0) atomicAdd(&g_par_prof[16 + (k)], (unsigned long long)(t_ - setup_t)); setup_t = t_; } }
+#define SETUP_DECL    uint64_t setup_t = __builtin_readcyclecounter()
+#else
+#define SETUP_MARK(k)
+#define SETUP_DECL
+#endif
+
+
+// lanes below this one that are set in m
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// build_table for a whole wavefront (T = 64), same tables, same verdicts.  Everything the lanes have to agree on
+// comes from ballots, so it lives in scalar registers and is worked out by the scalar unit: the histogram
+// (no LDS atomics: 64 lanes on 15 counters serialise), the layout, the next code of every length.  Codes much
+// shorter than the main table's index (dozens of copies of one entry) are written by all lanes together, one
+// symbol after the other; the rest by their own lanes (at most four copies each).
+// Lengths in registers: lane l holds the length of symbol l + 64 j in lj (0 where there is no such symbol).
+template <class F, bool LITLEN>
+__device__ __noinline__ int build_table_wave(typename F::entry_t *table, uint32_t l0, uint32_t l1, uint32_t l2, uint32_t l3,
+                                             uint32_t l4, int lane) {
+  constexpr int      mainbits  = LITLEN ? F::LIT_BITS : F::DIST_BITS;
+  constexpr uint32_t cap       = LITLEN ? F::LIT_CAP : F::DIST_CAP;
+  constexpr int      ref_bits  = LITLEN ? REF_LIT_BITS : REF_DIST_BITS;
+  constexpr uint32_t ref_cap   = LITLEN ? REF_LIT_CAP : REF_DIST_CAP;
+  constexpr uint32_t main_size = 1u << mainbits;
+  constexpr int      NB        = LITLEN ? 5 : 1;     // batches of 64 symbols (at most 288 / 32)
+
+  const uint32_t len5[5] = {l0, l1, l2, l3, l4};
+  uint32_t       len[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) len[j] = len5[j];
+  uint32_t count[16], first[16];
+#pragma unroll
+  for (int l = 1; l <= 15; l++) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) c += (uint32_t)__popcll(__ballot(len[j] == (uint32_t)l));
+    count[l] = c;
+  }
+  uint32_t used = main_size;
+  uint32_t cls_lo[16], cls_hi[16], cls_at[16];
+  {
+    int      left = 1;
+    uint32_t code = 0, prev = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) {
+      left = (left << 1) - (int)count[l];
+      if (left < 0) return BUILD_REJECT;
+      code = (code + prev) << 1;                     // count[0] left out: canonical codes
+      prev = count[l];
+      first[l] = code;
+    }
+    uint32_t ref_used = 1u << ref_bits, ref_claim = 0x7fffffffu, claim = 0x7fffffffu;
+#pragma unroll
+    for (int l = 15; l >= 1; l--) {
+      const uint32_t c = count[l];
+      if (l > ref_bits && c) {
+        uint32_t lo = first[l] >> (l - ref_bits), hi = (first[l] + c - 1) >> (l - ref_bits);
+        if (hi >= ref_claim) hi = ref_claim - 1;
+        if (hi + 1 > lo) ref_used += (hi + 1 - lo) << (l - ref_bits);
+        ref_claim = lo < ref_claim ? lo : ref_claim;
+      }
+      cls_lo[l] = 1, cls_hi[l] = 0, cls_at[l] = 0;   // empty class
+      if (l > mainbits && c) {
+        const uint32_t clo = first[l] >> (l - mainbits);
+        uint32_t       chi = (first[l] + c - 1) >> (l - mainbits);
+        if (chi >= claim) chi = claim - 1;
+        if (chi + 1 > clo) {
+          cls_lo[l] = clo;
+          cls_hi[l] = chi;
+          cls_at[l] = used;
+          used += (chi + 1 - clo) << (l - mainbits);
+        }
+        claim = clo < claim ? clo : claim;
+      }
+    }
+    if (ref_used > ref_cap) return BUILD_REJECT;     // infl.c:524-525
+    if (used > cap) return BUILD_NOFIT;
+  }
+
+  for (uint32_t i = lane; i < used; i += 64) table[i] = 0;
+  group_sync();
+  // main-table entries that point at subtables
+#pragma unroll
+  for (int l = mainbits + 1; l <= 15; l++) {
+    if (cls_hi[l] >= cls_lo[l])
+      for (uint32_t p = cls_lo[l] + (uint32_t)lane; p <= cls_hi[l]; p += 64)
+        table[__brev(p) >> (32 - mainbits)] =
+            F::sub_entry(cls_at[l] + ((p - cls_lo[l]) << (l - mainbits)), (uint32_t)(l - mainbits));
+  }
+  group_sync();
+
+  // canonical codes in symbol order (first[] now counts on), entries written at once
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    uint32_t code = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; l++) {
+      const uint64_t m = __ballot(len[j] == (uint32_t)l);
+      if (len[j] == (uint32_t)l) code = first[l] + lanes_below(m);
+      first[l] += (uint32_t)__popcll(m);
+    }
+    const uint32_t s = (uint32_t)lane + 64u * j, ln = len[j];
+    const typename F::entry_t e = !ln ? 0 : LITLEN ? F::lit_entry(s, ln) : F::dist_entry(s, ln);
+    const uint32_t r = ln ? __brev(code) >> (32 - ln) : 0u;
+    const bool     wide = e && ln + 2u < (uint32_t)mainbits;          // more than four copies
+    if (e && !wide) {
+      if (ln <= (uint32_t)mainbits) {
+        for (uint32_t i = r; i < main_size; i += 1u << ln) table[i] = e;
+      } else {
+        const uint32_t me  = table[r & (main_size - 1u)];
+        const uint32_t at  = F::sub_at(me);
+        const uint32_t end = 1u << F::sub_bits(me);
+        for (uint32_t i = r >> mainbits; i < end; i += 1u << (ln - mainbits)) table[at + i] = e;
+      }
+    }
+    for (uint64_t todo = __ballot(wide); todo; todo &= todo - 1) {
+      const uint32_t b  = (uint32_t)__builtin_ctzll(todo);
+      const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)b), rb = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)b),
+                     lb = (uint32_t)__builtin_amdgcn_readlane((int)ln, (int)b);
+      for (uint32_t i = rb + ((uint32_t)lane << lb); i < main_size; i += 64u << lb) table[i] = (typename F::entry_t)eb;
+    }
+  }
+  group_sync();
+  return BUILD_OK;
+}
+
 //
 // Code lengths come from LDS (`lens`) or, when `lens` is null, from `lens_reg`:
 // byte j of that register is the length of symbol lig + j * T (at most 32
@@ -442,6 +587,17 @@ template <int T, class F>
 __device__ __noinline__ int build_table(typename F::entry_t *table, const uint8_t *lens,
                                         uint32_t lens_reg, uint32_t nsyms, bool litlen,
                                         StreamLds<F> &L, int lig, int gshift) {
+  if constexpr (T == 64) {
+    group_sync();                                    // the lengths were written by other lanes
+    uint32_t len[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const uint32_t s = (uint32_t)lig + 64u * j;
+      len[j] = s >= nsyms ? 0u : lens ? lens[s] : j < 4 ? (lens_reg >> (8 * j)) & 0xffu : 0u;
+    }
+    return litlen ? build_table_wave<F, true>(table, len[0], len[1], len[2], len[3], len[4], lig)
+                  : build_table_wave<F, false>(table, len[0], 0, 0, 0, 0, lig);
+  }
   const int      mainbits  = litlen ? F::LIT_BITS : F::DIST_BITS;
   const uint32_t cap       = litlen ? F::LIT_CAP : F::DIST_CAP;
   const int      ref_bits  = litlen ? REF_LIT_BITS : REF_DIST_BITS;
@@ -560,6 +716,34 @@ __device__ __noinline__ int build_table(typename F::entry_t *table, const uint8_
 // Rejects an over-subscribed set, accepts an incomplete one.
 template <int T>
 __device__ __noinline__ bool build_clen_table(uint16_t *tab, uint64_t packed, int lig) {
+  if constexpr (T == 64) {                           // lane s holds symbol s; ballots instead of counting loops
+    const uint32_t len = lig < 19 ? (uint32_t)(packed >> (3 * lig)) & 7u : 0u;
+    int      left = 1;
+    uint32_t code = 0, prev = 0, mine = 0;
+#pragma unroll
+    for (int l = 1; l < 8; l++) {
+      const uint64_t m = __ballot(len == (uint32_t)l);
+      const uint32_t c = (uint32_t)__popcll(m);
+      left = (left << 1) - (int)c;
+      if (left < 0) return false;
+      code = (code + prev) << 1;
+      prev = c;
+      if (len == (uint32_t)l) mine = code + lanes_below(m);
+    }
+    group_sync();
+    ((uint32_t *)tab)[lig] = 0;
+    ((uint32_t *)tab)[lig + 64] = 0;
+    group_sync();
+    const uint32_t e = ((uint32_t)lig << 8) | len, r = len ? __brev(mine) >> (32 - len) : 0u;
+    for (uint64_t todo = __ballot(len != 0); todo; todo &= todo - 1) {
+      const uint32_t b  = (uint32_t)__builtin_ctzll(todo);
+      const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)b), rb = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)b),
+                     lb = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)b);
+      for (uint32_t i = rb + ((uint32_t)lig << lb); i < 256; i += 64u << lb) tab[i] = (uint16_t)eb;
+    }
+    group_sync();
+    return true;
+  }
   uint32_t cnt[8];
 #pragma unroll
   for (int l = 0; l < 8; l++) cnt[l] = 0;
@@ -625,15 +809,144 @@ __device__ __noinline__ int setup_fixed(StreamLds<F> &L, int lig, int gshift) {
 // INFL_D_NOFIT.
 constexpr int INFL_D_NOFIT = 100;   // valid so far, but the tables exceed the compact format
 
+// The dynamic block header for a whole wavefront on the register-window reader.  Everything in a header is the
+// same for all lanes, so it is kept in scalar registers and worked out by the scalar unit (the vector pipe is
+// what the decoder runs short of): the bit reservoir is refilled with v_readlane from the window, the 256-entry
+// code-length table sits in two vector registers per lane (four 16-bit entries) and is read with v_readlane, the
+// lengths go into five vector registers (lane l, register j = symbol l + 64 j) with v_writelane and from there
+// straight into the table builders.  Same rules and the same order of tests as setup_dynamic below.
+struct ScalarBits {
+  uint64_t bits;
+  uint32_t n, idx;       // idx: next word of the reader's window
+  int32_t  left;         // input bits not yet consumed (rd_left)
+};
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void sb_open(ScalarBits &s, const FastReader<64> &r) {
+  s.bits = ((uint64_t)uniform((uint32_t)(r.bits >> 32)) << 32) | uniform((uint32_t)r.bits);
+  s.n    = uniform(r.n);
+  s.idx  = uniform((r.ipos - r.wbase) >> 2);
+  s.left = (int32_t)uniform((uint32_t)rd_left(r));
+}
+__device__ __forceinline__ void sb_fill(ScalarBits &s, FastReader<64> &r) {
+  if (s.n < 32) {
+    if (s.idx >= 64u) {
+      rd_promote(r);
+      s.idx -= 64u;
+    }
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)r.cur, (int)s.idx);
+    s.bits |= (uint64_t)w << s.n;
+    s.n += 32;
+    s.idx++;
+  }
+}
+__device__ __forceinline__ void sb_drop(ScalarBits &s, uint32_t k) {
+  s.bits >>= k;
+  s.n -= k;
+  s.left -= (int32_t)k;
+}
+__device__ __forceinline__ void sb_close(const ScalarBits &s, FastReader<64> &r) {
+  r.bits = s.bits;
+  r.n    = s.n;
+  r.ipos = r.wbase + 4u * s.idx;
+}
+
+template <class F>
+__device__ __noinline__ int setup_dynamic_wave(FastReader<64> &r, StreamLds<F> &L, int lane) {
+  ScalarBits b;
+  sb_open(b, r);
+  sb_fill(b, r);
+  if (b.left < 14) return INFL_D_NEED_INPUT;
+  const uint32_t hlit  = ((uint32_t)b.bits & 31u) + 257u;
+  const uint32_t hdist = (((uint32_t)b.bits >> 5) & 31u) + 1u;
+  const uint32_t hclen = (((uint32_t)b.bits >> 10) & 15u) + 4u;
+  const uint32_t n     = hlit + hdist;
+  sb_drop(b, 14);
+  const uint64_t order_tail = 0xF1E2D3C4B5A69780ull;   // see setup_dynamic
+  uint64_t packed = 0;
+  for (uint32_t i = 0; i < hclen; i++) {
+    const uint32_t sym = i < 3 ? 16u + i : (uint32_t)(order_tail >> (4 * (i - 3))) & 15u;
+    sb_fill(b, r);
+    if (b.left < 3) return INFL_D_NEED_INPUT;
+    packed |= (uint64_t)((uint32_t)b.bits & 7u) << (3 * sym);
+    sb_drop(b, 3);
+  }
+  uint16_t *ctab = L.ctab();
+  if (!build_clen_table<64>(ctab, packed, lane)) return INFL_D_INVALID;
+  // entries lane, lane + 64, lane + 128, lane + 192
+  const uint32_t t01 = (uint32_t)ctab[lane] | ((uint32_t)ctab[lane + 64] << 16);
+  const uint32_t t23 = (uint32_t)ctab[lane + 128] | ((uint32_t)ctab[lane + 192] << 16);
+
+  uint32_t len[5] = {0, 0, 0, 0, 0};
+  uint32_t prev = 0;
+  for (uint32_t i = 0; i < n;) {
+    sb_fill(b, r);
+    if (b.left < 7) return INFL_D_NEED_INPUT;
+    const uint32_t x = (uint32_t)b.bits & 255u;
+    const uint32_t w = (x & 128u) ? (uint32_t)__builtin_amdgcn_readlane((int)t23, (int)(x & 63u))
+                                  : (uint32_t)__builtin_amdgcn_readlane((int)t01, (int)(x & 63u));
+    const uint32_t e = (x & 64u) ? w >> 16 : w & 0xffffu;
+    if (!(e & 255u)) return INFL_D_INVALID;
+    const uint32_t sym = e >> 8;
+    sb_drop(b, e & 255u);
+    if (sym < 16) {
+      const uint32_t at = i & 63u;
+      switch (i >> 6) {                              // scalar branches
+        case 0: len[0] = (uint32_t)lane == at ? sym : len[0]; break;
+        case 1: len[1] = (uint32_t)lane == at ? sym : len[1]; break;
+        case 2: len[2] = (uint32_t)lane == at ? sym : len[2]; break;
+        case 3: len[3] = (uint32_t)lane == at ? sym : len[3]; break;
+        default: len[4] = (uint32_t)lane == at ? sym : len[4]; break;
+      }
+      prev = sym;
+      i++;
+    } else {
+      // 16: the length before, 3..6 times (2 more bits); 17: zero 3..10 times (3 bits); 18: zero 11..138 times (7 bits)
+      const uint32_t xb = sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+      if (b.left < (int32_t)xb) return INFL_D_NEED_INPUT;
+      if (sym == 16 && i == 0) return INFL_D_INVALID;
+      const uint32_t rep = (sym == 18 ? 11u : 3u) + ((uint32_t)b.bits & ((1u << xb) - 1u));
+      sb_drop(b, xb);
+      if (i + rep > n) return INFL_D_INVALID;
+      if (sym == 16) {
+        if (prev) {
+#pragma unroll
+          for (int j = 0; j < 5; j++)
+            if ((i + rep - 1u) >> 6 >= (uint32_t)j && i >> 6 <= (uint32_t)j)       // scalar
+              len[j] = (uint32_t)lane + 64u * j - i < rep ? prev : len[j];
+        }
+      } else {
+        prev = 0;
+      }
+      i += rep;
+    }
+  }
+  sb_close(b, r);
+
+  int rc = build_table_wave<F, true>(L.lit, len[0], len[1], len[2], len[3], (uint32_t)lane + 256u < hlit ? len[4] : 0u, lane);
+  if (rc == BUILD_OK) {
+    // the distance lengths are symbols hlit .. hlit + hdist - 1, all in the fifth register: lane d takes symbol hlit + d
+    const uint32_t dl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((hlit - 256u + (uint32_t)lane) & 63u) << 2), (int)len[4]);
+    rc = build_table_wave<F, false>(L.dist, (uint32_t)lane < hdist ? dl : 0u, 0, 0, 0, 0, lane);
+  }
+  return rc == BUILD_OK ? INFL_D_OK : rc == BUILD_REJECT ? INFL_D_INVALID : INFL_D_NOFIT;
+}
+
+template <class R> struct IsWindowReader64 { static constexpr bool value = false; };
+template <> struct IsWindowReader64<FastReader<64>> { static constexpr bool value = true; };
+
 template <int T, class F, class R>
 __device__ __forceinline__ int setup_dynamic(R &r, StreamLds<F> &L, int lig, int gshift) {
+  if constexpr (T == 64 && IsWindowReader64<R>::value) return setup_dynamic_wave<F>(r, L, lig);
+  SETUP_DECL;
   rd_fill(r);
-  if (rd_real(r) < 14) return INFL_D_NEED_INPUT;
+  int32_t left = rd_left(r);                         // input bits not yet consumed: what the reference's tests are about
+  if (left < 14) return INFL_D_NEED_INPUT;
   uint32_t hlit  = ((uint32_t)r.bits & 31u) + 257u;
   uint32_t hdist = (((uint32_t)r.bits >> 5) & 31u) + 1u;
   uint32_t hclen = (((uint32_t)r.bits >> 10) & 15u) + 4u;
   uint32_t n     = hlit + hdist;
   rd_drop(r, 14);
+  left -= 14;
 
   // code-length alphabet order 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
   // (apicommon.h:52): the 16 entries after the first three, one per nibble
@@ -642,60 +955,60 @@ __device__ __forceinline__ int setup_dynamic(R &r, StreamLds<F> &L, int lig, int
   for (uint32_t i = 0; i < hclen; i++) {
     uint32_t sym = i < 3 ? 16u + i : (uint32_t)(order_tail >> (4 * (i - 3))) & 15u;
     rd_fill(r);
-    if (rd_real(r) < 3) return INFL_D_NEED_INPUT;
+    if (left < 3) return INFL_D_NEED_INPUT;
     packed |= (uint64_t)((uint32_t)r.bits & 7u) << (3 * sym);
     rd_drop(r, 3);
+    left -= 3;
   }
 
   uint16_t *ctab = L.ctab();
   uint8_t  *lens = L.lens();
+  SETUP_MARK(0);
   if (!build_clen_table<T>(ctab, packed, lig)) return INFL_D_INVALID;
 
-  for (int s = lig; s < 320; s += T) lens[s] = 0;
+  for (int s = lig; s < 80; s += T) ((uint32_t *)lens)[s] = 0;       // 320 lengths
   group_sync();
+  SETUP_MARK(1);
 
   uint32_t prev = 0;
   for (uint32_t i = 0; i < n;) {
     rd_fill(r);
-    if (rd_real(r) < 7) return INFL_D_NEED_INPUT;
+    if (left < 7) return INFL_D_NEED_INPUT;
     uint32_t e = ctab[(uint32_t)r.bits & 255u];
     if (!(e & 255u)) return INFL_D_INVALID;
     uint32_t sym = e >> 8;
     rd_drop(r, e & 255u);
+    left -= (int32_t)(e & 255u);
     if (sym < 16) {
       if (lig == 0) lens[i] = (uint8_t)sym;
       prev = sym;
       i++;
-    } else if (sym == 16) {
-      if (rd_real(r) < 2) return INFL_D_NEED_INPUT;
-      if (i == 0) return INFL_D_INVALID;
-      uint32_t rep = 3u + ((uint32_t)r.bits & 3u);
-      rd_drop(r, 2);
-      if (i + rep > n) return INFL_D_INVALID;
-      if ((uint32_t)lig < rep) lens[i + lig] = (uint8_t)prev;   // rep <= 6 <= T
-      i += rep;
-    } else if (sym == 17) {
-      if (rd_real(r) < 3) return INFL_D_NEED_INPUT;
-      uint32_t rep = 3u + ((uint32_t)r.bits & 7u);
-      rd_drop(r, 3);
-      if (i + rep > n) return INFL_D_INVALID;
-      i += rep;
-      prev = 0;
     } else {
-      if (rd_real(r) < 7) return INFL_D_NEED_INPUT;
-      uint32_t rep = 11u + ((uint32_t)r.bits & 127u);
-      rd_drop(r, 7);
+      // 16: the length before, 3..6 times (2 more bits); 17: zero 3..10 times (3 bits); 18: zero 11..138 times (7 bits)
+      const uint32_t xb = sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+      if (left < (int32_t)xb) return INFL_D_NEED_INPUT;
+      if (sym == 16 && i == 0) return INFL_D_INVALID;
+      const uint32_t rep = (sym == 18 ? 11u : 3u) + ((uint32_t)r.bits & ((1u << xb) - 1u));
+      rd_drop(r, xb);
+      left -= (int32_t)xb;
       if (i + rep > n) return INFL_D_INVALID;
+      if (sym == 16) {
+        if ((uint32_t)lig < rep) lens[i + lig] = (uint8_t)prev;   // rep <= 6 <= T
+      } else {
+        prev = 0;
+      }
       i += rep;
-      prev = 0;
     }
   }
 
+  SETUP_MARK(2);
   int rc = build_table<T, F>(L.lit, lens, 0, hlit, true, L, lig, gshift);
+  SETUP_MARK(3);
   if (rc == BUILD_OK) {
     uint32_t dl = dist_lens_to_reg<T>(lens, hlit, hdist, lig);
     rc = build_table<T, F>(L.dist, nullptr, dl, hdist, false, L, lig, gshift);
   }
+  SETUP_MARK(4);
   return rc == BUILD_OK ? INFL_D_OK : rc == BUILD_REJECT ? INFL_D_INVALID : INFL_D_NOFIT;
 }
 
@@ -959,11 +1272,14 @@ struct alignas(16) ParLds {
 
 // Optional cycle accounting of the phases (diagnostic builds only: make prof).
 #ifdef DEFL_PAR_PROFILE
-__device__ unsigned long long g_par_prof[32];
 #define PROF_DECL      uint64_t prof_t = __builtin_readcyclecounter(), prof_acc[10] = {}, prof_cnt[4] = {}, prof_hist[12] = {}
 #define PROF_MARK(k)   { uint64_t t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; }
 #define PROF_COUNT(k, v) prof_cnt[k] += (v)
+#ifdef DEFL_PAR_PROFILE_SETUP
+#define PROF_HIST(v)
+#else
 #define PROF_HIST(v)   { _Pragma("unroll") for (int k_ = 0; k_ < 12; k_++) prof_hist[k_] += ((v) == k_ || (k_ == 11 && (v) > 11)); }
+#endif
 #define PROF_BAIL(k)   { if (lane == 0) atomicAdd(&g_par_prof[k], 1ull); }
 #define PROF_FLUSH     if (lane == 0) { for (int k_ = 0; k_ < 10; k_++) atomicAdd(&g_par_prof[k_], prof_acc[k_]); \
                                         for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_par_prof[10 + k_], prof_cnt[k_]); \

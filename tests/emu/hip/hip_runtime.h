@@ -96,6 +96,15 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
   const int got = emu::bpermute((from < 0 ? lane : from) << 2, src);   // every lane takes part
   return (from >= 0 && ((row_mask >> row) & 1)) ? got : old;
 }
+// v_mbcnt_lo / v_mbcnt_hi: base + the set bits of the mask half that belong to lanes below this one
+static inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t m, uint32_t base) {
+  const int lane = emu::t_lane & 63;
+  return base + (uint32_t)__builtin_popcount(lane >= 32 ? m : m & ((1u << lane) - 1u));
+}
+static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t m, uint32_t base) {
+  const int lane = emu::t_lane & 63;
+  return base + (uint32_t)__builtin_popcount(lane <= 32 ? 0u : m & ((1u << (lane - 32)) - 1u));
+}
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_readlane(v, l) emu::bpermute((int)((l) << 2), (int)(v))
 

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8192)
     ap.add_argument("--pool", type=int, default=256)
     ap.add_argument("--workload", default="text", choices=["text", "noise", "fixed", "png", "mixed", "files"])
+    ap.add_argument("--size", type=int, default=0, help="text: decompressed bytes per stream (default 64 KiB)")
     args = ap.parse_args()
     from defl_amd import capi
     eng = capi.load()
@@ -35,7 +36,7 @@ def main():
     fn.argtypes = [C.POINTER(C.c_ulonglong)]
     eng.lib.infl_gpu_set_table_variant(2)
     if args.workload == "text":
-        comps = bench.build_pool(0, args.pool, 4)
+        comps = bench.build_pool(0, [args.size or bench.STREAM_BYTES] * args.pool, 4)
     elif args.workload == "fixed":
         import zlib
         comps = [wl.deflate(wl.text_stream(i), 6, True, zlib.Z_FIXED) for i in range(args.pool)]
@@ -63,7 +64,7 @@ def main():
         rng = np.random.default_rng(8)
         comps = [wl.deflate(bytes(rng.integers(32, 96, 65536, dtype=np.uint8))) for i in range(args.pool)]
     if args.workload not in ("png", "mixed", "files"):
-        caps = [bench.STREAM_BYTES] * len(comps)
+        caps = [(args.size if args.workload == "text" and args.size else bench.STREAM_BYTES)] * len(comps)
     reps = (args.streams + args.pool - 1) // args.pool
     comps = (comps * reps)[: args.streams]
     caps = (caps * reps)[: args.streams]
@@ -101,6 +102,10 @@ def main():
     if v[30]:
         print("steps %d per stream, %.1f %% of them with a second-level lookup by some lane"
               % (v[30] / n, 100 * v[31] / v[30]))
+    if os.environ.get("DEFL_PROFILE_SETUP"):      # a build with -DDEFL_PAR_PROFILE_SETUP: the slots hold the set-up split
+        names = ["header + code-length lengths", "code-length table", "code-length loop", "literal/length table", "distance table"]
+        print("block setup split (cycles per stream): " + "; ".join("%s %.0f" % (nm, v[16 + k] / n) for k, nm in enumerate(names)))
+        return
     print("full scans per round (share of rounds): " +
           "  ".join("%d:%.2f%%" % (k, 100 * v[16 + k] / rounds) for k in range(12)))
 
