@@ -26,6 +26,17 @@ def test_c_caller_compiles_and_links_against_the_library(engine):
     assert "libdefl_amd.so" in out and "not found" not in out.split("libdefl_amd.so")[1].split("\n")[0]
 
 
+def test_include_cost_program_runs():
+    """tests/c_dropin/include_cost.c: infl_include() timed from C (fresh streams and reused ones); host only."""
+    import json
+    _build()
+    p = subprocess.run([os.path.join(CDIR, "include_cost"), "256", "48000"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1000:]
+    r = json.loads(p.stdout)
+    assert r["streams"] == 256 and r["bytes"] == 256 * 48000 and r["include_calls"] > 256 * 6
+    assert 0 < r["ns_per_include_reused"] < 1e6 and 0 < r["ns_per_include"] < 1e6
+
+
 @pytest.mark.gpu
 def test_c_caller_decodes_the_golden_pairs(engine):
     if not os.path.exists(EXE):          # (built on the CPU beforehand; the GPU box only runs it)

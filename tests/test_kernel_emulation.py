@@ -310,3 +310,24 @@ def test_emulated_png_unfilter():
                               in_len=[len(good), len(good), len(good) - 1, len(good), len(good), len(good)],
                               in_status=[0, 0, 0, -1, 0, 0])
     assert list(st) == [0, -1, -1, -1, -1, -1] and out[0] == pixels
+
+
+def test_emulated_png_unfilter_geometry_sweep():
+    """Row lengths around the kernel's 16-byte pieces, its 256-byte windows and the 16-byte fast-path limit,
+    scanline counts around its bands of 64, random pixel sizes and filter types, random bytes."""
+    oracle = oracle_lib.load()
+    rng = np.random.default_rng(77)
+    filtered, geom, want = [], [], []
+    for rb in (1, 2, 3, 4, 15, 16, 17, 31, 32, 33, 63, 64, 65, 191, 192, 193, 255, 256, 257, 271, 272, 273, 511, 512, 513, 700):
+        for rows in (1, 2, 63, 64, 65, 128, 129):
+            if rb * rows > 60000:
+                continue
+            bpp = int(rng.choice([1, 2, 3, 4, 6, 8]))
+            d = rng.integers(0, 256, size=(rows, rb + 1), dtype=np.uint8)
+            d[:, 0] = rng.integers(0, 5, size=rows)
+            rc, w_ = oracle.png_unfilter(d.tobytes(), rows, rb, bpp)
+            assert rc == 0
+            filtered.append(d.tobytes()); geom.append((rows, rb, bpp)); want.append(w_)
+    out, st = emu_lib.run_png(filtered, geom)
+    bad = [g for g, a, b, s in zip(geom, out, want, st) if a != b or s != 0]
+    assert not bad, bad[:10]
