@@ -37,6 +37,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec), GB/s
 FULL_STREAMS = {"text64k": 65536, "mixed": 1048576}
 
 
+RESULT_OUT = sys.stdout
+
+
 def note(msg):
     """Progress on stderr (stdout carries only the JSON line)."""
     if os.environ.get("RANK", "0") == "0":
@@ -230,6 +233,14 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(relaunch(args, sys.argv[1:]))
 
+    # Exactly one line goes to stdout: the result.  Whatever a library prints there (the gloo transport announces
+    # its connections on stdout, from C++) is sent to stderr by pointing descriptor 1 at it; the result line is
+    # written to a private copy of the original descriptor.
+    global RESULT_OUT
+    sys.stdout.flush()
+    RESULT_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -400,7 +411,8 @@ def main():
             note("cpu baseline on %d threads" % threads)
             k = min(pool, 1024)
             res["cpu_baseline"] = cpu_baseline(comps[:k], sizes[:k], oracle, threads, 12.0)
-        print(json.dumps(res), flush=True)
+        RESULT_OUT.write(json.dumps(res) + "\n")
+        RESULT_OUT.flush()
     if world > 1:
         dist.destroy_process_group()
 
