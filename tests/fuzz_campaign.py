@@ -3,7 +3,9 @@
 (diagnostic: `python tests/fuzz_campaign.py [first seed] [seeds] [seconds]` on a GPU box).  Streams that
 stress the parallel decoder's special paths (rounds cut short, serial stretches, failing streams
 reported by the parallel pass): text with runs, near fixed-length codes, fixed-Huffman blocks, flush
-points; mutated, truncated, with too little output space.  Both entry points are compared, bit for bit."""
+points; mutated, truncated, with too little output space.  Both entry points are compared, bit for bit.
+With DEFL_FUZZ_HEADERS=1 the streams are small and the damage goes into their first 150 bytes: the block headers
+(code-length code, repeat codes, table acceptance) get most of it."""
 import os
 import random
 import sys
@@ -64,12 +66,22 @@ def main():
     t0, total = time.time(), 0
     for seed in range(first, first + seeds):
         rng, nrng = random.Random(seed), np.random.default_rng(seed)
-        bases = [(r, compress(r, rng)) for r in (make_raw(rng, nrng) for _ in range(10))]
+        headers = os.environ.get("DEFL_FUZZ_HEADERS") == "1"
+        if headers:
+            raws = [make_raw(rng, nrng)[: rng.randint(200, 6000)] for _ in range(40)]
+            bases = [(r, compress(r, rng)) for r in raws]
+        else:
+            bases = [(r, compress(r, rng)) for r in (make_raw(rng, nrng) for _ in range(10))]
         streams, caps = [], []
-        for _ in range(200):
+        for _ in range(2000 if headers else 200):
             raw, comp = rng.choice(bases)
             m, what = bytearray(comp), rng.random()
-            if what < 0.3:
+            if headers and len(m) > 4:
+                for _ in range(rng.randint(1, 3)):
+                    m[rng.randrange(2, min(150, len(m)))] ^= 1 << rng.randrange(8)
+                if what < 0.15:
+                    m = m[: rng.randrange(2, min(200, len(m)) + 1)]
+            elif what < 0.3:
                 for _ in range(rng.randint(1, 4)):
                     m[rng.randrange(min(2, len(m) - 1), len(m))] ^= 1 << rng.randrange(8)
             elif what < 0.5:
