@@ -36,6 +36,9 @@ extern "C" {
 /* same, for a stream the parallel pass found to fail: only the last pass (tables in the
    reference's geometry, exact failure result) needs to look at it */
 #define INFL_STATUS_DEFERRED_FAILING 0x40000001
+/* same, and the parallel pass has left where the last pass can take over: outlen[i] = output position, detail[i] =
+   bit position of the block's header, inpos[i] = bit position of a symbol of that block (0 = its first) */
+#define INFL_STATUS_DEFERRED_RESUME 0x40000002
 
 /* kernel flag bits: bit 0 = zlib wrapper; INFL_F_PROGRESS = when a stream stops
    for lack of input or output space, report the output position it reached in

@@ -1473,10 +1473,16 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
 // code or a code past the end of the input on the true chain, a distance before the output
 // start, more output than capacity: the reason itself is not worked out here); INFL_D_NOFIT
 // when the stream has to be decoded by the serial passes.
+//
+// NOTE (the pass that looks at failing streams a second time): when the block fails, lane 0 leaves in note[1] /
+// note[2] a symbol boundary of the true chain in front of the failure and the output position there, so that the
+// pass that works out the exact result goes on from it instead of from the start.  The first pass is compiled
+// without: its loops sit at the register limit and any addition moves the compiler's spills into them.
+template <bool NOTE>
 __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t *dst, uint32_t &pos_io,
                                                     uint32_t cap, const uint16_t *lit,
                                                     const uint16_t *dist, ParLds &P, int lane,
-                                                    bool expect_short) {
+                                                    bool expect_short, uint32_t *note) {
   uint32_t       pos        = pos_io;
   uint32_t       B          = r.ipos * 8u - r.n;     // bit position of the block's first symbol
   const uint32_t total_bits = r.ilen * 8u;
@@ -1492,6 +1498,10 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
   // symbol boundary some PAR_STRETCH bits on; the rounds go on behind it.  Sets B and `done`.
   auto serial_stretch = [&](uint32_t from) -> bool {        // false: the stream fails
     PROF_BAIL(28);
+    if (NOTE && lane == 0) {
+      note[1] = from;
+      note[2] = pos;
+    }
     group_sync();
     rd_seek(r, r.src + (from >> 3));
     rd_fill(r);
@@ -1617,6 +1627,10 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
     const uint32_t why        = !cut && first_stop < 64 ? wave_read(sc.stop, first_stop) : 0u;
     if (why == 2) {                                  // malformed on the true chain
       PROF_BAIL(29);
+      if (NOTE && lane == 0) {
+        note[1] = B;
+        note[2] = pos;
+      }
       return INFL_D_INVALID;
     }
     if (why == 3 && first_stop < DEFL_PAR_STRETCH_LANES) {                // very long matches: the serial copy loops do better
@@ -1629,7 +1643,13 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
       uint32_t t = wave_read(cum, (uint32_t)lane >= dlt ? lane - dlt : 0);
       if ((uint32_t)lane >= dlt) cum += t;
     }
-    if (wave_read(cum, nact - 1u) > cap - pos) return INFL_D_INVALID;   // more output than capacity
+    if (wave_read(cum, nact - 1u) > cap - pos) {     // more output than capacity
+      if (NOTE && lane == 0) {
+        note[1] = B;
+        note[2] = pos;
+      }
+      return INFL_D_INVALID;
+    }
     PROF_MARK(3);
 
     // The round's output is produced in groups of up to 16 consecutive chains whose bytes fit
@@ -1697,7 +1717,16 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
           }
         }
       }
-      if (__ballot(bad)) return INFL_D_INVALID;
+      if (__ballot(bad)) {                           // (nothing of this group has been written yet)
+        if constexpr (NOTE) {
+          const uint32_t from = wave_read(start, a);
+          if (lane == 0) {
+            note[1] = from;
+            note[2] = pos;
+          }
+        }
+        return INFL_D_INVALID;
+      }
       group_sync();
       PROF_MARK(4);
 
@@ -1822,16 +1851,27 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
 
 // Block loop (infl.c:1063-1092).  SYM selects the symbol loop: 0 = huffman_block (any table
 // format, exact failure reasons), 1 = huffman_block_compact, 2 = huffman_block_parallel.
+// SYM 3 = 2 for the pass that looks at failing streams a second time: lane 0 notes where a later pass can take the
+// stream up again: note[0] = bit position of the header of the block in hand, note[1] = bit position of a symbol of
+// that block on the true chain (0 = the block's first), note[2] = the output position there, note[3] = 1.
 template <int T, class F, class R, int SYM>
 __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uint32_t cap,
                                           StreamLds<F> &L, ParLds *par, int lig, int gshift,
-                                          uint64_t &fuel) {
+                                          uint64_t &fuel, uint32_t *note) {
   bool     fixed_ready = false;
   bool     short_block = false;                    // the Huffman block before this one took under 1024 input bits
   uint32_t bfinal = 0;
   while (!bfinal) {
     if (fuel-- == 0) return INFL_D_INTERNAL;
     rd_fill(r);
+    if constexpr (SYM == 3) {
+      if (lig == 0) {
+        note[0] = r.ipos * 8u - r.n;
+        note[1] = 0;
+        note[2] = pos;
+        note[3] = 1;
+      }
+    }
     if (r.n < 3) return INFL_D_NEED_INPUT;
     bfinal = (uint32_t)r.bits & 1u;
     uint32_t btype = ((uint32_t)r.bits >> 1) & 3u;
@@ -1856,16 +1896,16 @@ __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uin
 #endif
         rc = setup_dynamic<T, F>(r, L, lig, gshift);
 #ifdef DEFL_PAR_PROFILE
-        if (SYM == 2 && lig == 0) atomicAdd(&g_par_prof[14], (unsigned long long)(__builtin_readcyclecounter() - setup_t0));
+        if (SYM >= 2 && lig == 0) atomicAdd(&g_par_prof[14], (unsigned long long)(__builtin_readcyclecounter() - setup_t0));
 #endif
       }
 #ifdef DEFL_PAR_PROFILE
-      if (SYM == 2 && rc == INFL_D_NOFIT && lig == 0) atomicAdd(&g_par_prof[15], 1ull);   // tables too large for the compact format
+      if (SYM >= 2 && rc == INFL_D_NOFIT && lig == 0) atomicAdd(&g_par_prof[15], 1ull);   // tables too large for the compact format
 #endif
       if (rc == INFL_D_OK) {
-        if constexpr (SYM == 2) {
+        if constexpr (SYM >= 2) {
           const uint32_t at = r.ipos * 8u - r.n;
-          rc = huffman_block_parallel(r, dst, pos, cap, L.lit, L.dist, *par, lig, short_block);
+          rc = huffman_block_parallel<SYM == 3>(r, dst, pos, cap, L.lit, L.dist, *par, lig, short_block, note);
           short_block = r.ipos * 8u - r.n - at < 1024u;
         } else if constexpr (SYM == 1) {
           rc = huffman_block_compact<T>(r, dst, pos, cap, L.lit, L.dist, lig) == COMPACT_END ? INFL_D_OK
@@ -1907,13 +1947,15 @@ template <int T, class F, class R, int SYM>
 __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srclen, uint8_t *dst,
                                               uint32_t cap, bool zlib, StreamLds<F> &L,
                                               ParLds *par, int lig, int gshift,
-                                              uint32_t &outlen, uint32_t &pos, const uint8_t *&cur) {
+                                              uint32_t &outlen, uint32_t &pos, const uint8_t *&cur,
+                                              uint32_t *note = nullptr) {
   outlen = 0;
   pos    = 0;
   cur    = src;
+  if (SYM == 3 && lig == 0) note[3] = 0;
   if (srclen == 0) return INFL_D_OK;               // infl.c:1547-1550
   if (SYM != 0 && srclen < 8) return INFL_D_NOFIT; // the fast reader needs a few bytes
-  if (SYM == 2 && srclen >= (1u << 28)) return INFL_D_NOFIT;   // 32-bit bit positions
+  if (SYM >= 2 && srclen >= (1u << 28)) return INFL_D_NOFIT;   // 32-bit bit positions
 
   const uint8_t *p = src, *end = src + srclen;
   uint64_t fuel = (uint64_t)srclen * 8u + 64u;     // every block consumes >= 1 input bit
@@ -1960,10 +2002,67 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
     p += 2;
   }
   rd_seek(r, p);
-  rc  = block_loop<T, F, R, SYM>(r, dst, pos, cap, L, par, lig, gshift, fuel);
+  rc  = block_loop<T, F, R, SYM>(r, dst, pos, cap, L, par, lig, gshift, fuel, note);
+  if (SYM == 3 && outlen && lig == 0) note[3] = 0;   // (a stored prefix has been published: that stream starts over)
   if (rc == INFL_D_OK && rd_overrun(r)) rc = INFL_D_NEED_INPUT;
   cur = rd_byte_ptr(r);
   if (rc == INFL_D_OK) outlen = pos;
+  return rc;
+}
+
+
+// The last pass's way into a stream that the parallel pass has found to fail (INFL_STATUS_DEFERRED_RESUME): the
+// output up to `pos` is in place, the block whose header stands at bit position `hdr` holds the failure, and `bit` is
+// a symbol boundary of that block in front of it (0 = the block's first symbol).  Builds the block's tables again and
+// decodes on from there, one symbol after the other, to the exact result a decode from the start would give.
+template <int T>
+__device__ __forceinline__ int inflate_from(const uint8_t *src, uint32_t srclen, uint8_t *dst, uint32_t cap,
+                                            uint32_t hdr, uint32_t bit, uint32_t &pos, StreamLds<RefFmt> &L, int lig,
+                                            int gshift, const uint8_t *&cur) {
+  typedef RefFmt F;
+  Reader r;
+  r.end = src + srclen;
+  uint64_t fuel = (uint64_t)srclen * 8u + 64u;
+  int      rc;
+  rd_seek(r, src + (hdr >> 3));
+  rd_fill(r);
+  rd_drop(r, hdr & 7u);
+  for (bool first = true;; first = false) {
+    if (fuel-- == 0) {
+      rc = INFL_D_INTERNAL;
+      break;
+    }
+    rd_fill(r);
+    if (r.n < 3) {
+      rc = INFL_D_NEED_INPUT;
+      break;
+    }
+    const uint32_t bfinal = (uint32_t)r.bits & 1u, btype = ((uint32_t)r.bits >> 1) & 3u;
+    rd_drop(r, 3);
+    if (btype == 0) {
+      rc = stored_block<T>(r, dst, pos, cap, lig);
+    } else if (btype == 3) {
+      rc = INFL_D_INVALID;
+    } else {
+      if (btype == 1) {
+        const int b = setup_fixed<T, F>(L, lig, gshift);
+        rc = b == BUILD_OK ? INFL_D_OK : INFL_D_INTERNAL;
+      } else {
+        rc = setup_dynamic<T, F>(r, L, lig, gshift);
+        if (rc == INFL_D_NOFIT) rc = INFL_D_INTERNAL;
+      }
+      if (rc == INFL_D_OK) {
+        if (first && bit) {
+          rd_seek(r, src + (bit >> 3));
+          rd_fill(r);
+          rd_drop(r, bit & 7u);
+        }
+        rc = huffman_block<T, F>(r, dst, pos, cap, L, lig, fuel);
+      }
+    }
+    if (rc != INFL_D_OK || bfinal) break;
+  }
+  cur = rd_byte_ptr(r);
   return rc;
 }
 
@@ -1992,12 +2091,17 @@ __device__ __forceinline__ void mirror_out(uint8_t *to, const uint8_t *from, uin
 // MODE 0: decode every stream and write its result.
 // MODE 1: first pass with the compact tables.  A stream that completes writes
 //         its result; any other stream is marked INFL_STATUS_DEFERRED.
-// MODE 2: last pass: only streams marked INFL_STATUS_DEFERRED or INFL_STATUS_DEFERRED_FAILING are decoded.
+// MODE 2: last pass: only streams marked INFL_STATUS_DEFERRED, INFL_STATUS_DEFERRED_FAILING or
+//         INFL_STATUS_DEFERRED_RESUME are decoded (the last kind from where the parallel pass says).
 // MODE 3: like MODE 1, but a whole wavefront decodes each Huffman block in parallel (T = 64).
 // MODE 4: like MODE 1, but only for streams marked INFL_STATUS_DEFERRED (by MODE 3; a stream it
 //         found to fail carries INFL_STATUS_DEFERRED_FAILING and waits for MODE 2).
+// MODE 5: MODE 3 once more for the streams marked INFL_STATUS_DEFERRED_FAILING, this time noting where the
+//         failure lies: the mark becomes INFL_STATUS_DEFERRED_RESUME and MODE 2 goes on from there instead of
+//         decoding the stream from its start, one symbol after the other (launched only when the caller asked
+//         for detail codes or positions: a failing 64 KiB stream costs 2 ms instead of 15).
 template <int T, class F, int MODE>
-__global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(64, (MODE == 3 || MODE == 5) ? 4 : 1) void infl_batch_kernel(const uint8_t *__restrict__ src,
                                                         const uint64_t *__restrict__ src_off,
                                                         uint8_t *__restrict__ dst,
                                                         const uint64_t *__restrict__ dst_off,
@@ -2009,13 +2113,18 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
                                                         uint8_t *__restrict__ mirror,
                                                         const uint32_t *__restrict__ skip) {
   constexpr int  G    = 64 / T;                    // streams per wavefront
-  constexpr int  SYM  = (MODE == 1 || MODE == 4) ? 1 : MODE == 3 ? 2 : 0;
-  static_assert(MODE != 3 || T == 64, "the parallel block decoder uses the whole wavefront");
+  constexpr int  SYM  = (MODE == 1 || MODE == 4) ? 1 : MODE == 3 ? 2 : MODE == 5 ? 3 : 0;
+  static_assert((MODE != 3 && MODE != 5) || T == 64, "the parallel block decoder uses the whole wavefront");
   __shared__ StreamLds<F> lds[G];
-  ParLds *parp = nullptr;
-  if constexpr (MODE == 3) {
+  ParLds   *parp = nullptr;
+  uint32_t *note = nullptr;
+  if constexpr (MODE == 3 || MODE == 5) {
     __shared__ ParLds par;
     parp = &par;
+  }
+  if constexpr (MODE == 5) {
+    __shared__ uint32_t note_buf[4];
+    note = note_buf;
   }
 
   const int      lane   = threadIdx.x;
@@ -2025,9 +2134,20 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
   const uint64_t i      = (uint64_t)blockIdx.x * G + group;
 
   if (i >= n) return;
-  if (MODE == 2 || MODE == 4) {
+  bool     resume = false;
+  uint32_t resume_hdr = 0, resume_bit = 0, resume_pos = 0;
+  if (MODE == 2 || MODE == 4 || MODE == 5) {
     const int32_t mark = status[i];
-    const bool    mine = mark == INFL_STATUS_DEFERRED || (MODE == 2 && mark == INFL_STATUS_DEFERRED_FAILING);
+    const bool    mine = MODE == 5 ? mark == INFL_STATUS_DEFERRED_FAILING
+                                   : mark == INFL_STATUS_DEFERRED ||
+                                         (MODE == 2 && (mark == INFL_STATUS_DEFERRED_FAILING || mark == INFL_STATUS_DEFERRED_RESUME));
+    if (MODE == 2 && mark == INFL_STATUS_DEFERRED_RESUME) {          // (set only when `detail` exists)
+      resume     = true;
+      resume_pos = outlen[i];
+      resume_hdr = (uint32_t)detail[i];
+      if (inpos) resume_bit = inpos[i];
+      else __builtin_memcpy(&resume_bit, dst + dst_off[i] + resume_pos, 4);   // parked behind the output so far
+    }
     group_sync();                                    // every lane has looked before one of them writes the result
     if (!mine) return;
   }
@@ -2047,15 +2167,38 @@ __global__ __launch_bounds__(64, MODE == 3 ? 4 : 1) void infl_batch_kernel(const
   uint32_t       out = 0, pos = 0;
   const uint8_t *cur = nullptr;
   int rc;
-  if constexpr (SYM != 0)
+  if constexpr (SYM != 0) {
     rc = inflate_stream<T, F, FastReader<T>, SYM>(src + s0, (uint32_t)(s1 - s0), dst + d0,
                                                   (uint32_t)(d1 - d0), (flags & 0xff) == 1,
                                                   lds[group], parp, lig,
-                                                  gshift, out, pos, cur);
-  else
+                                                  gshift, out, pos, cur, note);
+  } else if (MODE == 2 && resume) {
+    if constexpr (MODE == 2) {
+      pos = resume_pos;
+      rc  = inflate_from<T>(src + s0, (uint32_t)(s1 - s0), dst + d0, (uint32_t)(d1 - d0), resume_hdr, resume_bit, pos,
+                            lds[group], lig, gshift, cur);
+      if (rc == INFL_D_OK) out = pos;
+    }
+  } else {
     rc = inflate_stream<T, F, Reader, 0>(src + s0, (uint32_t)(s1 - s0), dst + d0,
                                          (uint32_t)(d1 - d0), (flags & 0xff) == 1, lds[group],
                                          nullptr, lig, gshift, out, pos, cur);
+  }
+  if constexpr (MODE == 5) {
+    // Three numbers tell the last pass where to take the stream up again: outlen[i], detail[i] and inpos[i]; without
+    // an inpos array the third one is parked in the four bytes behind the output so far (a failing stream's output
+    // area holds nothing a caller may rely on), if there are four.  Anything else leaves the mark as it is.
+    if (lig == 0 && rc != INFL_D_OK && rc != INFL_D_NOFIT && rc != INFL_D_INTERNAL && note[3] && detail != nullptr &&
+        (inpos != nullptr || (uint32_t)(d1 - d0) - note[2] >= 4u)) {
+      const uint32_t bit = note[1];
+      outlen[i] = note[2];
+      detail[i] = (int32_t)note[0];
+      if (inpos) inpos[i] = bit;
+      else __builtin_memcpy(dst + d0 + note[2], &bit, 4);
+      status[i] = INFL_STATUS_DEFERRED_RESUME;
+    }
+    return;
+  }
   if ((MODE == 1 || MODE == 3 || MODE == 4) && rc != INFL_D_OK) {
     // The parallel pass reports a stream that certainly fails by itself when the caller wants
     // the reference's result only (UNZ_ERR and the output position infl() leaves, which does not
@@ -2759,6 +2902,9 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
     LAUNCH(64, CompactFmt, 3);  \
     if (variant == 2) {         \
       LAUNCH(T, CompactFmt, 4); \
+      if (detail) {             \
+        LAUNCH(64, CompactFmt, 5); \
+      }                         \
       LAUNCH(T, RefFmt, 2);     \
     }                           \
   }

@@ -1,35 +1,126 @@
 // Host-side emulation harness: compiles defl_amd/csrc/infl_kernels.hip with g++ (through the
-// stand-in hip/hip_runtime.h next to this file) and runs each workgroup as 64 host threads.
-// Lanes of a group meet at a real barrier wherever the kernel has a wavefront fence, a
-// wave_barrier or a ballot, which is where the hardware's lockstep makes their memory
-// operations ordered.  Test infrastructure only.
-#include <pthread.h>
+// stand-in hip/hip_runtime.h next to this file) and runs every lane of a workgroup as a fiber.
+// Lanes of a group meet at a barrier wherever the kernel has a wavefront fence, a wave_barrier or
+// a ballot, which is where the hardware's lockstep makes their memory operations ordered; between
+// two barriers one lane runs to the end before the next starts, so code that leans on lockstep
+// without saying so (a missing fence) reads stale data here and fails its test.  Test infrastructure only.
+#include <sanitizer/asan_interface.h>
+#include <stdio.h>
+#include <stdlib.h>
 
-#include <thread>
 #include <vector>
 
 #include "hip/hip_runtime.h"
 
+// Lanes are fibers of ONE host thread, switched by hand at the collectives: a wavefront's 64 lanes reach a
+// barrier by 64 switches of a few nanoseconds each (one operating-system thread per lane and a pthread barrier
+// per collective cost a futex round trip per lane and barrier: minutes for the suite, many more on a busy
+// machine).  A lane runs until it meets a barrier that is not yet complete, then the next lane of the workgroup
+// runs; every lane of a group makes the same sequence of collective calls (that is what lockstep means).
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+asm(R"(
+  .text
+  .globl emu_switch
+  .type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+  .size emu_switch,.-emu_switch
+)");
+
 namespace emu {
-// One barrier per collective.  Every lane of a group makes the same sequence of collective calls
-// (that is what lockstep means), so a per-thread call counter tells all of them which of a few
-// rotating buffers the call uses; a buffer is written again only after a later barrier has shown
-// that every lane is done reading it.
 struct Group {
-  pthread_barrier_t     bar;
+  unsigned              size = 64, count = 0, gen = 0;   // cooperative barrier: arrivals of this generation
   std::atomic<uint64_t> mask[3];
   Group() { for (auto &m : mask) m.store(0); }
 };
+struct Fiber {
+  void    *sp = nullptr;
+  char    *stack = nullptr;
+  dim3     tid, bid, gdim;
+  Group   *group = nullptr;
+  int      lane = 0;
+  unsigned ballots = 0, permutes = 0;
+  bool     done = false;
+};
 int g_slots[2][1024];   // ds_bpermute exchange buffers, one slot per thread of the workgroup (read within the wavefront)
-pthread_barrier_t *g_block_bar = nullptr;   // __syncthreads of the workgroup that is running
-thread_local dim3     t_threadIdx, t_blockIdx, t_gridDim;
-thread_local Group   *t_group = nullptr;
-thread_local int      t_lane  = 0;
-thread_local unsigned t_ballots = 0, t_permutes = 0;
-int                   g_lanes_per_group = 64;
+dim3     t_threadIdx, t_blockIdx, t_gridDim;   // the running lane's view (set at every switch)
+Group   *t_group = nullptr;
+int      t_lane  = 0;
+unsigned t_ballots = 0, t_permutes = 0;
+int      g_lanes_per_group = 64;
 
-void group_barrier() { pthread_barrier_wait(&t_group->bar); }
-void block_barrier() { pthread_barrier_wait(g_block_bar); }
+static std::vector<Fiber>           g_fibers;
+static int                          g_cur = -1;
+static void                        *g_main_sp = nullptr;
+static Group                        g_block_group;
+static const std::function<void()> *g_fn = nullptr;
+static constexpr size_t             kStack = 512u << 10;
+static std::vector<char *>          g_stacks;          // one per lane, kept from workgroup to workgroup
+
+static void load(int k) {
+  Fiber &f = g_fibers[k];
+  g_cur = k;
+  t_threadIdx = f.tid; t_blockIdx = f.bid; t_gridDim = f.gdim;
+  t_group = f.group; t_lane = f.lane; t_ballots = f.ballots; t_permutes = f.permutes;
+}
+static void save() {
+  Fiber &f = g_fibers[g_cur];
+  f.ballots = t_ballots; f.permutes = t_permutes;
+}
+// Runs the next lane that has not finished; back to the launcher when none is left.
+static void yield() {
+  const int n = (int)g_fibers.size(), me = g_cur;
+  save();
+  for (int d = 1; d <= n; d++) {
+    const int k = (me + d) % n;
+    if (!g_fibers[k].done) {
+      if (k == me) return;                           // (the caller checks whether it may go on)
+      void **slot = &g_fibers[me].sp;
+      load(k);
+      emu_switch(slot, g_fibers[k].sp);
+      return;
+    }
+  }
+  void **slot = &g_fibers[me].sp;
+  g_cur = -1;
+  emu_switch(slot, g_main_sp);
+}
+static void wait_at(Group &g) {
+  const unsigned gen = g.gen;
+  if (++g.count == g.size) {
+    g.count = 0;
+    g.gen++;
+    return;
+  }
+  while (g.gen == gen) {
+    const int before = g_cur;
+    yield();
+    if (g.gen == gen && g_cur == before) {
+      bool others = false;
+      for (size_t k = 0; k < g_fibers.size(); k++) others |= (int)k != before && !g_fibers[k].done;
+      if (!others) {
+        fprintf(stderr, "emu: lane %d waits at a barrier that the finished lanes of its group never reached\n", before);
+        abort();
+      }
+    }
+  }
+}
+void group_barrier() { wait_at(*t_group); }
+void block_barrier() { wait_at(g_block_group); }
 
 uint64_t ballot(bool pred) {
   const unsigned k = t_ballots++ % 3u;
@@ -49,28 +140,40 @@ int bpermute(int byte_addr, int value) {
   return g_slots[k][(t_lane & ~63) + ((byte_addr >> 2) & 63)];
 }
 
+static void fiber_entry() {
+  (*g_fn)();
+  g_fibers[g_cur].done = true;
+  for (;;) yield();                                  // never comes back here
+}
+
 void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
   const int T = g_lanes_per_group, ngroups = (int)block / T;
+  g_fn = &fn;
   for (unsigned b = 0; b < grid; b++) {
     std::vector<Group> groups(ngroups);
-    for (auto &g : groups) pthread_barrier_init(&g.bar, nullptr, T);
-    pthread_barrier_t block_bar;
-    pthread_barrier_init(&block_bar, nullptr, block);
-    g_block_bar = &block_bar;
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < block; t++)
-      th.emplace_back([&, t] {
-        t_threadIdx = dim3(t);
-        t_blockIdx  = dim3(b);
-        t_gridDim   = dim3(grid);
-        t_lane      = (int)t;
-        t_group     = &groups[t / T];
-        t_ballots = t_permutes = 0;
-        fn();
-      });
-    for (auto &x : th) x.join();
-    for (auto &g : groups) pthread_barrier_destroy(&g.bar);
-    pthread_barrier_destroy(&block_bar);
+    for (auto &g : groups) g.size = (unsigned)T;
+    g_block_group.size = block;
+    g_block_group.count = g_block_group.gen = 0;
+    g_fibers.assign(block, Fiber());
+    for (unsigned t = 0; t < block; t++) {
+      Fiber &f = g_fibers[t];
+      if (g_stacks.size() <= t) g_stacks.push_back((char *)malloc(kStack));
+      f.stack = g_stacks[t];
+      __asan_unpoison_memory_region(f.stack, kStack);   // (what the frames of the lane before left poisoned)
+      f.tid = dim3(t); f.bid = dim3(b); f.gdim = dim3(grid);
+      f.lane = (int)t;
+      f.group = &groups[t / T];
+      // a stack on which emu_switch finds six saved registers and the address to "return" to; a function is
+      // entered with the stack pointer 8 below a multiple of 16
+      uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+      void **sp = (void **)(top - 8);
+      *--sp = (void *)&fiber_entry;
+      for (int r = 0; r < 6; r++) *--sp = nullptr;
+      f.sp = sp;
+    }
+    load(0);
+    emu_switch(&g_main_sp, g_fibers[0].sp);          // returns when every lane has finished
+    g_fibers.clear();
   }
 }
 }  // namespace emu

@@ -32,9 +32,9 @@ inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 1; return hipSu
 
 namespace emu {
 struct Group;
-extern thread_local dim3   t_threadIdx, t_blockIdx, t_gridDim;
-extern thread_local Group *t_group;
-extern thread_local int    t_lane;
+extern dim3   t_threadIdx, t_blockIdx, t_gridDim;   // the running lane's (lanes are fibers of one host thread)
+extern Group *t_group;
+extern int    t_lane;
 void     group_barrier();
 void     block_barrier();
 uint64_t ballot(bool pred);

@@ -457,3 +457,40 @@ def test_streaming_resumes_inside_blocks(engine, oracle):
             break
     assert (rc == capi.UNZ_OK) == (want_rc == 0)
     lib.infl_destroy(st)
+
+
+def test_failing_streams_taken_up_where_they_fail(engine, oracle):
+    """Large streams that fail somewhere inside (cut off, damaged, too little room): with detail codes asked for,
+    the parallel pass notes where and the last pass goes on from there; status, output position and detail code
+    must be what the oracle gives for a decode from the start, at every cut."""
+    rng = random.Random(21)
+    streams, caps = [], []
+    bases = [(wl.text_stream(600 + k, 65536), None) for k in range(4)]
+    bases.append((wl.png_like(3), None))
+    bases.append((bytes(rng.randrange(32, 40) for _ in range(50000)), None))
+    bases = [(r, wl.deflate(r, 6 if k % 2 else 1)) for k, (r, _) in enumerate(bases)]
+    # several blocks per stream: the note names the block the failure lies in
+    multi = zlib.compressobj(6)
+    parts = [multi.compress(bases[0][0][:20000]), multi.flush(zlib.Z_FULL_FLUSH), multi.compress(bases[1][0][:30000]),
+             multi.flush(zlib.Z_SYNC_FLUSH), multi.compress(bases[2][0][:15536]), multi.flush()]
+    bases.append((bases[0][0][:20000] + bases[1][0][:30000] + bases[2][0][:15536], b"".join(parts)))
+    for raw, comp in bases:
+        for _ in range(12):
+            kind = rng.randrange(4)
+            c, cap = bytearray(comp), len(raw)
+            if kind == 0:
+                c = c[: rng.randrange(8, len(c) - 1)]
+            elif kind == 1:
+                at = rng.randrange(40, len(c) - 4)
+                c[at] ^= 1 << rng.randrange(8)
+            elif kind == 2:
+                cap = rng.randrange(0, len(raw))
+            else:
+                c = c[: rng.randrange(8, len(c) - 1)]
+                cap = rng.randrange(len(raw) // 2, len(raw) + 1)
+            streams.append(bytes(c)); caps.append(cap)
+    status, outlen, detail = _check_batch(engine, oracle, streams, caps, 1, 16, "failing streams", 2)
+    assert (status != 0).sum() >= len(streams) * 3 // 4
+    for i, (c, cap) in enumerate(zip(streams, caps)):
+        rc, pos, _, det = oracle.infl(c, cap, 1)
+        assert (int(status[i]), int(outlen[i]), int(detail[i])) == (rc, pos, det), (i, len(c), cap)
