@@ -68,6 +68,7 @@ static int                          g_cur = -1;
 static void                        *g_main_sp = nullptr;
 static Group                        g_block_group;
 static const std::function<void()> *g_fn = nullptr;
+static int                          g_dir = 1;         // EMU_ORDER=reverse: lanes take their turns from 63 down
 static constexpr size_t             kStack = 512u << 10;
 static std::vector<char *>          g_stacks;          // one per lane, kept from workgroup to workgroup
 
@@ -86,7 +87,7 @@ static void yield() {
   const int n = (int)g_fibers.size(), me = g_cur;
   save();
   for (int d = 1; d <= n; d++) {
-    const int k = (me + d) % n;
+    const int k = ((me + g_dir * d) % n + n) % n;
     if (!g_fibers[k].done) {
       if (k == me) return;                           // (the caller checks whether it may go on)
       void **slot = &g_fibers[me].sp;
@@ -171,8 +172,9 @@ void launch(unsigned grid, unsigned block, const std::function<void()> &fn) {
       for (int r = 0; r < 6; r++) *--sp = nullptr;
       f.sp = sp;
     }
-    load(0);
-    emu_switch(&g_main_sp, g_fibers[0].sp);          // returns when every lane has finished
+    const int first = g_dir > 0 ? 0 : (int)block - 1;
+    load(first);
+    emu_switch(&g_main_sp, g_fibers[first].sp);      // returns when every lane has finished
     g_fibers.clear();
   }
 }
@@ -289,6 +291,9 @@ static int main_png(char **argv) {
 
 int main(int argc, char **argv) {
   if (argc < 6) return 2;
+  // Between two barriers the lanes run one after the other; in which order must not matter to a correct kernel.
+  const char *order = getenv("EMU_ORDER");
+  if (order && !strcmp(order, "reverse")) emu::g_dir = -1;
   if (!strcmp(argv[3], "resume")) return main_resume(argc, argv);
   if (!strcmp(argv[3], "png")) return main_png(argv);
   FILE *f = fopen(argv[1], "rb");
