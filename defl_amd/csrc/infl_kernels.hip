@@ -850,8 +850,44 @@ __device__ __forceinline__ void sb_close(const ScalarBits &s, FastReader<64> &r)
   r.ipos = r.wbase + 4u * s.idx;
 }
 
+// (The reader goes in and comes back by value: a reader whose address is handed to an out-of-line function lives in
+// memory for the whole kernel, and the symbol-by-symbol loops that read it at every step ran at half their speed.)
+struct ReaderAfterHeader {
+  uint64_t bits;
+  uint32_t n, ipos, wbase, cur, nxt, nxtsh;
+  int      rc;
+};
 template <class F>
-__device__ __noinline__ int setup_dynamic_wave(FastReader<64> &r, StreamLds<F> &L, int lane) {
+__device__ __forceinline__ int setup_dynamic_wave_body(FastReader<64> &r, StreamLds<F> &L, int lane);
+
+template <class F>
+__device__ __noinline__ ReaderAfterHeader setup_dynamic_wave_call(FastReader<64> r, StreamLds<F> *L, int lane) {
+  ReaderAfterHeader o;
+  o.rc    = setup_dynamic_wave_body<F>(r, *L, lane);
+  o.bits  = r.bits;
+  o.n     = r.n;
+  o.ipos  = r.ipos;
+  o.wbase = r.wbase;
+  o.cur   = r.cur;
+  o.nxt   = r.nxt;
+  o.nxtsh = r.nxtsh;
+  return o;
+}
+template <class F>
+__device__ __forceinline__ int setup_dynamic_wave(FastReader<64> &r, StreamLds<F> &L, int lane) {
+  const ReaderAfterHeader o = setup_dynamic_wave_call<F>(r, &L, lane);
+  r.bits  = o.bits;
+  r.n     = o.n;
+  r.ipos  = o.ipos;
+  r.wbase = o.wbase;
+  r.cur   = o.cur;
+  r.nxt   = o.nxt;
+  r.nxtsh = o.nxtsh;
+  return o.rc;
+}
+
+template <class F>
+__device__ __forceinline__ int setup_dynamic_wave_body(FastReader<64> &r, StreamLds<F> &L, int lane) {
   ScalarBits b;
   sb_open(b, r);
   sb_fill(b, r);
