@@ -39,6 +39,9 @@ extern "C" {
 /* same, and the parallel pass has left where the last pass can take over: outlen[i] = output position, detail[i] =
    bit position of the block's header, inpos[i] = bit position of a symbol of that block (0 = its first) */
 #define INFL_STATUS_DEFERRED_RESUME 0x40000002
+// decoded by the windowed serial pass; the last pass turns it into 0 (until then the mark tells the window's other
+// wavefronts that the stream was one of the marked ones)
+#define INFL_STATUS_DEFERRED_DONE 0x40000003
 
 /* kernel flag bits: bit 0 = zlib wrapper; INFL_F_PROGRESS = when a stream stops
    for lack of input or output space, report the output position it reached in

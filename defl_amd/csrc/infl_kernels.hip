@@ -1286,6 +1286,10 @@ constexpr int      PAR_MAX_FIXUP = DEFL_PAR_MAX_FIXUP;   // counting scans per r
 #define DEFL_PAR_STRETCH_LANES 8                     // a byte cap within this many lanes of a round: serial stretch
 #endif
 constexpr uint32_t PAR_STRETCH  = DEFL_PAR_STRETCH;              // input bits of a serial stretch (doubled while they follow each other)
+#ifndef DEFL_PAR_MIN_INPUT
+#define DEFL_PAR_MIN_INPUT 256
+#endif
+constexpr uint32_t PAR_MIN_INPUT = DEFL_PAR_MIN_INPUT;   // input bytes below which a stream is left to the serial pass
 constexpr int      PAR_U        = 4;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
@@ -1990,7 +1994,9 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
   cur    = src;
   if (SYM == 3 && lig == 0) note[3] = 0;
   if (srclen == 0) return INFL_D_OK;               // infl.c:1547-1550
-  if (SYM != 0 && srclen < 8) return INFL_D_NOFIT; // the fast reader needs a few bytes
+  // The fast reader needs a few bytes.  The parallel decoder leaves short streams to the serial pass behind it, several
+  // to a wavefront: one of its rounds costs the same for three busy lanes as for 64, and so does the set-up of a block.
+  if (SYM != 0 && srclen < (SYM >= 2 ? PAR_MIN_INPUT : 8u)) return INFL_D_NOFIT;
   if (SYM >= 2 && srclen >= (1u << 28)) return INFL_D_NOFIT;   // 32-bit bit positions
 
   const uint8_t *p = src, *end = src + srclen;
@@ -2185,6 +2191,10 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5) ? 4 : 1) void infl_bat
       else __builtin_memcpy(&resume_bit, dst + dst_off[i] + resume_pos, 4);   // parked behind the output so far
     }
     group_sync();                                    // every lane has looked before one of them writes the result
+    if (MODE == 2 && mark == INFL_STATUS_DEFERRED_DONE) {            // finished by the windowed serial pass
+      if (lig == 0) status[i] = 0;
+      return;
+    }
     if (!mine) return;
   }
 
@@ -2257,6 +2267,79 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5) ? 4 : 1) void infl_bat
   if (mirror) {
     group_sync();                                    // the lanes read what other lanes of the group wrote
     mirror_out<T>(mirror + d0, dst + d0, d0, produced, lig);
+  }
+}
+
+// The serial pass behind the parallel one (MODE 4 of infl_batch_kernel) for groups of 8 or 16 lanes.  The streams it is
+// for lie anywhere in the batch, often a few among many.  The wavefronts of a window of kDeferWindow streams share the
+// window's marked streams out by rank: the first wavefront's groups take the first 64 / T marked ones, the next
+// wavefront's the following ones, and a wavefront with nothing left ends at once; so no group idles beside a busy one
+// wherever neighbours are not all marked, and a window of marked streams only is handled as by the plain kernel.
+// A stream this pass cannot finish keeps its mark for the last pass; one it finishes gets INFL_STATUS_DEFERRED_DONE, which
+// the last pass (it looks at every stream) turns into 0.
+constexpr int kDeferWindow = 64;
+template <int T>
+__global__ __launch_bounds__(64, 1) void infl_deferred_window_kernel(const uint8_t *__restrict__ src,
+                                                                      const uint64_t *__restrict__ src_off,
+                                                                      uint8_t *__restrict__ dst,
+                                                                      const uint64_t *__restrict__ dst_off, int flags,
+                                                                      uint64_t n, int32_t *__restrict__ status,
+                                                                      uint32_t *__restrict__ outlen,
+                                                                      int32_t *__restrict__ detail,
+                                                                      uint32_t *__restrict__ inpos,
+                                                                      uint8_t *__restrict__ mirror,
+                                                                      const uint32_t *__restrict__ skip) {
+  typedef CompactFmt F;
+  constexpr int G = 64 / T;
+  static_assert(T <= kDeferWindow && kDeferWindow % T == 0 && kDeferWindow <= 64, "one mask word per window");
+  __shared__ StreamLds<F> lds[G];
+  const int lane = threadIdx.x, group = lane / T, lig = lane % T, gshift = group * T;
+
+  // every group works the marks out for itself (the same ones)
+  constexpr int  WPW    = kDeferWindow / G;          // wavefronts per window
+  const uint64_t base   = (uint64_t)(blockIdx.x / WPW) * kDeferWindow;
+  uint64_t       marked = 0;
+#pragma unroll
+  for (int w = 0; w < kDeferWindow; w += T) {
+    const uint64_t k    = base + (uint64_t)(w + lig);
+    const int32_t  mark = k < n ? status[k] : 0;
+    const bool     mine = mark == INFL_STATUS_DEFERRED || mark == INFL_STATUS_DEFERRED_DONE;
+    marked |= ((__ballot(mine) >> gshift) & ((1ull << T) - 1ull)) << w;
+  }
+  group_sync();                                      // every mark has been read before a result is written
+  // (the window's wavefronts take their turns in an order that changes from window to window: workgroups go to the
+  // chip's eight parts by their index, and the busy ones should not all have the same index modulo 8)
+  const int rank = (int)((blockIdx.x + blockIdx.x / WPW) % WPW) * G + group;
+  if ((int)__popcll(marked) <= rank) return;         // (a whole wavefront, or its last groups: nothing left for them)
+  for (int k = 0; k < rank; k++) marked &= marked - 1ull;
+  {
+    const uint64_t i = base + (uint64_t)__builtin_ctzll(marked);
+
+    uint64_t       s0 = src_off[i], s1 = src_off[i + 1];
+    const uint64_t d0 = dst_off[i], d1 = dst_off[i + 1];
+    if (skip) {                                      // a container header in front of the stream (gzip)
+      const uint64_t k = skip[i];
+      s0 = k < s1 - s0 ? s0 + k : s1;
+    }
+    uint32_t       out = 0, pos = 0;
+    const uint8_t *cur = nullptr;
+    const int rc = inflate_stream<T, F, FastReader<T>, 1>(src + s0, (uint32_t)(s1 - s0), dst + d0, (uint32_t)(d1 - d0),
+                                                          (flags & 0xff) == 1, lds[group], nullptr, lig, gshift, out, pos,
+                                                          cur);
+    if (rc == INFL_D_OK) {
+      if (lig == 0) {
+        // (not 0 yet: the window's other wavefronts, which may start much later, must still see that this stream was
+        // one of the marked ones, or they would count their ranks differently)
+        status[i] = INFL_STATUS_DEFERRED_DONE;
+        outlen[i] = out;
+        if (detail) detail[i] = rc;
+        if (inpos) inpos[i] = (uint32_t)(cur - (src + s0));
+      }
+      if (mirror) {
+        group_sync();                                // the lanes read what other lanes of the group wrote
+        mirror_out<T>(mirror + d0, dst + d0, d0, out, lig);
+      }
+    }
   }
 }
 
@@ -2909,12 +2992,17 @@ __global__ __launch_bounds__(64) void infl_png_unfilter_kernel(const uint8_t *in
 
 }  // namespace defl
 
+#ifndef DEFL_LAUNCH_GROUP
+#define DEFL_LAUNCH_GROUP(T)     // (the test suite's host-side emulation is told the lanes per stream of a launch here)
+#endif
+
 // variant 0: reference-geometry tables only (one launch).
 // variant 1: compact tables first, reference-geometry tables for what they defer (two launches).
 // variant 2: wavefront-parallel block decode first (one wavefront per stream); what it defers
 //            (anything malformed or out of space, tables too large for the compact format,
 //            tiny streams) goes through the two serial passes of variant 1 (three launches).
 // variant 3: diagnostic: the parallel pass alone; deferred streams keep INFL_STATUS_DEFERRED.
+// variant 4: diagnostic: the parallel pass and the serial pass behind it; what they leave keeps its mark.
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                                  uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
@@ -2924,11 +3012,23 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
   auto s = (const uint8_t *)src;
   auto d = (uint8_t *)dst;
   auto m = (uint8_t *)mirror;
-#define LAUNCH(T, FMT, MODE)                                                                   \
-  hipLaunchKernelGGL((defl::infl_batch_kernel<T, defl::FMT, MODE>),                            \
-                     dim3((unsigned)((n + (64 / T) - 1) / (64 / T))), dim3(64), 0, st, s, src_off, \
-                     d, dst_off, flags, n, status, outlen, detail, inpos, m, skip)
-#define LAUNCH_T(T)             \
+#define LAUNCH(T, FMT, MODE)                                                                     \
+  do {                                                                                           \
+    DEFL_LAUNCH_GROUP(T);                                                                        \
+    hipLaunchKernelGGL((defl::infl_batch_kernel<T, defl::FMT, MODE>),                            \
+                       dim3((unsigned)((n + (64 / T) - 1) / (64 / T))), dim3(64), 0, st, s, src_off, \
+                       d, dst_off, flags, n, status, outlen, detail, inpos, m, skip);            \
+  } while (0)
+#define LAUNCH_DEFERRED_PLAIN(T) LAUNCH(T, CompactFmt, 4)
+#define LAUNCH_DEFERRED_WINDOW(T)                                                                              \
+  do {                                                                                                         \
+    DEFL_LAUNCH_GROUP(T);                                                                                      \
+    hipLaunchKernelGGL((defl::infl_deferred_window_kernel<T>),                                                 \
+                       dim3((unsigned)((n + defl::kDeferWindow - 1) / defl::kDeferWindow * (defl::kDeferWindow / (64 / T)))), \
+                     dim3(64), 0, st, s,                                                                     \
+                       src_off, d, dst_off, flags, n, status, outlen, detail, inpos, m, skip);                 \
+  } while (0)
+#define LAUNCH_T(T, DEFERRED)   \
   if (variant == 0) {           \
     LAUNCH(T, RefFmt, 0);       \
   } else if (variant == 1) {    \
@@ -2936,8 +3036,10 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
     LAUNCH(T, RefFmt, 2);       \
   } else {                      \
     LAUNCH(64, CompactFmt, 3);  \
+    if (variant == 2 || variant == 4) { \
+      DEFERRED(T);              \
+    }                           \
     if (variant == 2) {         \
-      LAUNCH(T, CompactFmt, 4); \
       if (detail) {             \
         LAUNCH(64, CompactFmt, 5); \
       }                         \
@@ -2945,13 +3047,15 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
     }                           \
   }
   switch (lanes) {
-    case 64: LAUNCH_T(64) break;
-    case 32: LAUNCH_T(32) break;
-    case 16: LAUNCH_T(16) break;
-    case 8:  LAUNCH_T(8)  break;
+    case 64: LAUNCH_T(64, LAUNCH_DEFERRED_PLAIN) break;
+    case 32: LAUNCH_T(32, LAUNCH_DEFERRED_PLAIN) break;
+    case 16: LAUNCH_T(16, LAUNCH_DEFERRED_WINDOW) break;
+    case 8:  LAUNCH_T(8, LAUNCH_DEFERRED_WINDOW)  break;
     default: return -1;
   }
 #undef LAUNCH_T
+#undef LAUNCH_DEFERRED_WINDOW
+#undef LAUNCH_DEFERRED_PLAIN
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -9,7 +9,7 @@ oracle before a number is printed.
   png      4 096 PNG-like images (128x128 RGBA scanlines, zlib-6) fed as IDAT pieces with
            infl_include() and decoded with one infl_many() call (host path, PCIe inclusive)
   mixed    text streams with log-uniform sizes 1 KiB .. 256 KiB, sorted by size (config 5 shape)
-  runs, textruns, truncated, flushed, small, files, noisy, pngdev, host
+  runs, textruns, truncated, flushed, small, tiny, files, noisy, pngdev, host
            what real batches hold besides clean text: byte runs, text with runs spliced in, a
            damaged stream in 64, flush points every few bytes, streams of 1 / 4 / 16 KiB, slices of
            local binaries and scripts, near fixed-length codes, PNG-like scanlines kept on the
@@ -74,7 +74,7 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5, failing
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,truncated,flushed,small,files,noisy,pngdev,host,png")
+    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,truncated,flushed,small,tiny,files,noisy,pngdev,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
@@ -162,6 +162,21 @@ def main():
             comps = [wl.deflate(x) for x in raws]
             r = run_device(eng, oracle, comps, [size] * 512, 1, 5, int((64 << 20) // size // 512 * 4 * args.scale))
             print(json.dumps({"config": "text streams of %d bytes" % size, **r}), flush=True)
+    if "tiny" in which:
+        # records of a few hundred bytes: under 256 input bytes the serial pass takes them, several to a wavefront
+        for size in (128, 256, 512):
+            raws = [wl.text_stream(5000 + i, size) for i in range(512)]
+            comps = [wl.deflate(x) for x in raws]
+            r = run_device(eng, oracle, comps, [size] * 512, 1, 5, int(128 * args.scale))
+            print(json.dumps({"config": "text streams of %d bytes" % size, **r}), flush=True)
+        # a corpus with everything from tiny records to 64 KiB (log-uniform sizes, in no order)
+        rng = np.random.default_rng(11)
+        sizes = np.exp(rng.uniform(np.log(64), np.log(65536), 2048)).astype(np.int64)
+        raws = [wl.text_stream(6000 + i, int(sz)) for i, sz in enumerate(sizes)]
+        comps = [wl.deflate(x) for x in raws]
+        r = run_device(eng, oracle, comps, [len(x) for x in raws], 1, 5, int(16 * args.scale))
+        print(json.dumps({"config": "wide mix 64 B..64 KiB (log-uniform, unsorted; %d%% of the streams under 256 input bytes)"
+                                    % round(100.0 * sum(len(c) < 256 for c in comps) / len(comps)), **r}), flush=True)
     if "files" in which:
         # 64 KiB slices of binaries, libraries and scripts found on this machine, zlib level 6
         import glob

@@ -190,8 +190,7 @@ extern "C" int emu_infl_batch(const void *src, const uint64_t *src_off, void *ds
                               int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
                               uint32_t *inpos, int lanes, int variant, void *mirror) {
   // (detail and inpos may be NULL: the caller then wants the reference's result only)
-  if (variant >= 2) lanes = 64;   // the parallel pass is a 64-lane kernel; one group size per run here
-  emu::g_lanes_per_group = lanes;
+  emu::g_lanes_per_group = lanes;  // (every launch sets its own)
   return infl_launch_batch(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, variant,
                            mirror, nullptr, nullptr);
 }

@@ -35,6 +35,7 @@ struct Group;
 extern dim3   t_threadIdx, t_blockIdx, t_gridDim;   // the running lane's (lanes are fibers of one host thread)
 extern Group *t_group;
 extern int    t_lane;
+extern int    g_lanes_per_group;                     // lanes that share barriers, ballots and permutes (a stream's lanes)
 void     group_barrier();
 void     block_barrier();
 uint64_t ballot(bool pred);
@@ -46,6 +47,7 @@ void     launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 #define blockIdx emu::t_blockIdx
 #define gridDim emu::t_gridDim
 
+#define DEFL_LAUNCH_GROUP(T) emu::g_lanes_per_group = (T)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
   emu::launch((grid).x, (block).x, [=] { kern(__VA_ARGS__); })
 

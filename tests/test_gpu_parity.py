@@ -494,3 +494,33 @@ def test_failing_streams_taken_up_where_they_fail(engine, oracle):
     for i, (c, cap) in enumerate(zip(streams, caps)):
         rc, pos, _, det = oracle.infl(c, cap, 1)
         assert (int(status[i]), int(outlen[i]), int(detail[i])) == (rc, pos, det), (i, len(c), cap)
+
+
+@pytest.mark.parametrize("lanes", [16, 8])
+def test_short_streams_among_long_ones(engine, oracle, lanes):
+    """The parallel pass leaves streams of under 256 input bytes to the serial pass behind it, whose wavefronts share
+    the marked streams of a window of 64 out by rank.  20 000 streams: runs of short ones, runs of long ones, single
+    ones among the others, damaged, cut short and with too little room; the count is not a multiple of 64."""
+    rng = random.Random(320 + lanes)
+    base = []
+    for i in range(300):
+        raw = wl.text_stream(9000 + i, rng.choice([0, 1, 7, 40, 130, 260, 400, 520, 700, 1100, 2500, 9000]))
+        base.append((raw, wl.deflate(raw, rng.choice([1, 6, 9]), True, rng.choice([zlib.Z_DEFAULT_STRATEGY] * 3 + [zlib.Z_FIXED]))))
+    short = [b for b in base if len(b[1]) < 256]
+    long_ = [b for b in base if len(b[1]) >= 256]
+    assert len(short) > 100 and len(long_) > 80
+    streams, caps = [], []
+    while len(streams) < 20003:
+        kind, run = rng.randrange(4), rng.choice([1, 1, 2, 5, 17, 64, 150])
+        for _ in range(run):
+            raw, c = rng.choice(short if kind == 0 else long_ if kind == 1 else base)
+            what = rng.random()
+            if what < 0.05 and len(c) > 4:
+                b = bytearray(c); b[rng.randrange(2, len(b))] ^= 1 << rng.randrange(8); c = bytes(b)
+            elif what < 0.08:
+                c = c[: rng.randrange(0, len(c) + 1)]
+            streams.append(c)
+            caps.append(len(raw) if what < 0.95 else rng.randrange(0, len(raw) + 1))
+    streams, caps = streams[:20003], caps[:20003]
+    status, _, _ = _check_batch(engine, oracle, streams, caps, 1, lanes, "short among long", 2)
+    assert (status == 0).sum() > 15000 and (status != 0).sum() > 500

@@ -18,12 +18,20 @@ def main():
     ap.add_argument("--streams", type=int, default=65536)
     ap.add_argument("--distinct", type=int, default=512)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--sizes", type=str, default="", help="comma separated stream sizes")
+    ap.add_argument("--variant", type=int, default=-1, help="1 = the serial passes alone, 2 = parallel pass first")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per stream in the serial passes (8, 16, 32, 64)")
     a = ap.parse_args()
     eng = capi.load()
     lib = eng.lib
     assert lib.infl_gpu_init(0) == 0
+    if a.variant >= 0:
+        assert lib.infl_gpu_set_table_variant(a.variant) == a.variant
+    if a.lanes:
+        assert lib.infl_gpu_set_lanes_per_stream(a.lanes) == a.lanes
     out = {}
-    for size in ([a.size] if a.size else [1024, 4096, 16384]):
+    sizes = [int(x) for x in a.sizes.split(",")] if a.sizes else [a.size] if a.size else [1024, 4096, 16384]
+    for size in sizes:
         raws = [wl.text_stream(3000 + i, size) for i in range(a.distinct)]
         comps = [wl.deflate(r) for r in raws]
         n = a.streams
