@@ -5,7 +5,8 @@ stress the parallel decoder's special paths (rounds cut short, serial stretches,
 reported by the parallel pass): text with runs, near fixed-length codes, fixed-Huffman blocks, flush
 points; mutated, truncated, with too little output space.  Both entry points are compared, bit for bit.
 With DEFL_FUZZ_HEADERS=1 the streams are small and the damage goes into their first 150 bytes: the block headers
-(code-length code, repeat codes, table acceptance) get most of it."""
+(code-length code, repeat codes, table acceptance) get most of it.  DEFL_FUZZ_LANES = lanes per stream in the serial
+passes (default 16)."""
 import os
 import random
 import sys
@@ -93,7 +94,7 @@ def main():
             caps.append(rng.choice([len(raw), len(raw), len(raw) + 100, max(0, len(raw) - rng.randint(1, 5000)),
                                     rng.randint(0, len(raw))]))
         print("seed %d: %d streams, %d KB in" % (seed, len(streams), sum(map(len, streams)) >> 10), flush=True)
-        _check_batch(eng, oracle, streams, caps, 1, 16, "campaign seed %d" % seed, 2)
+        _check_batch(eng, oracle, streams, caps, 1, int(os.environ.get("DEFL_FUZZ_LANES", "16")), "campaign seed %d" % seed, 2)
         total += len(streams)
         if time.time() - t0 > budget:
             break
