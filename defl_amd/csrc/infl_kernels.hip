@@ -1290,6 +1290,10 @@ constexpr uint32_t PAR_STRETCH  = DEFL_PAR_STRETCH;              // input bits o
 #define DEFL_PAR_MIN_INPUT 256
 #endif
 constexpr uint32_t PAR_MIN_INPUT = DEFL_PAR_MIN_INPUT;   // input bytes below which a stream is left to the serial pass
+#ifndef DEFL_PAR_SHORT_BATCH
+#define DEFL_PAR_SHORT_BATCH 6144
+#endif
+constexpr uint64_t PAR_SHORT_BATCH = DEFL_PAR_SHORT_BATCH;   // ... in batches of at least this many streams
 constexpr int      PAR_U        = 4;                 // independent LDS/global accesses kept in flight
 constexpr uint32_t LK_LIT = 0x4000u, LK_EXT = 0x8000u;
 
@@ -1994,9 +1998,10 @@ __device__ __forceinline__ int inflate_stream(const uint8_t *src, uint32_t srcle
   cur    = src;
   if (SYM == 3 && lig == 0) note[3] = 0;
   if (srclen == 0) return INFL_D_OK;               // infl.c:1547-1550
-  // The fast reader needs a few bytes.  The parallel decoder leaves short streams to the serial pass behind it, several
-  // to a wavefront: one of its rounds costs the same for three busy lanes as for 64, and so does the set-up of a block.
-  if (SYM != 0 && srclen < (SYM >= 2 ? PAR_MIN_INPUT : 8u)) return INFL_D_NOFIT;
+  // The fast reader needs a few bytes.  In a batch that fills the device the parallel decoder leaves short streams to the
+  // serial pass behind it, several to a wavefront: one of its rounds costs the same for three busy lanes as for 64, and
+  // so does the set-up of a block.
+  if (SYM != 0 && srclen < ((SYM == 2 || SYM == 3) ? PAR_MIN_INPUT : 8u)) return INFL_D_NOFIT;   // (SYM 4: a small batch)
   if (SYM >= 2 && srclen >= (1u << 28)) return INFL_D_NOFIT;   // 32-bit bit positions
 
   const uint8_t *p = src, *end = src + srclen;
@@ -2143,7 +2148,7 @@ __device__ __forceinline__ void mirror_out(uint8_t *to, const uint8_t *from, uin
 //         decoding the stream from its start, one symbol after the other (launched only when the caller asked
 //         for detail codes or positions: a failing 64 KiB stream costs 2 ms instead of 15).
 template <int T, class F, int MODE>
-__global__ __launch_bounds__(64, (MODE == 3 || MODE == 5) ? 4 : 1) void infl_batch_kernel(const uint8_t *__restrict__ src,
+__global__ __launch_bounds__(64, (MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1) void infl_batch_kernel(const uint8_t *__restrict__ src,
                                                         const uint64_t *__restrict__ src_off,
                                                         uint8_t *__restrict__ dst,
                                                         const uint64_t *__restrict__ dst_off,
@@ -2155,12 +2160,15 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5) ? 4 : 1) void infl_bat
                                                         uint8_t *__restrict__ mirror,
                                                         const uint32_t *__restrict__ skip) {
   constexpr int  G    = 64 / T;                    // streams per wavefront
-  constexpr int  SYM  = (MODE == 1 || MODE == 4) ? 1 : MODE == 3 ? 2 : MODE == 5 ? 3 : 0;
-  static_assert((MODE != 3 && MODE != 5) || T == 64, "the parallel block decoder uses the whole wavefront");
+  // MODE 6 = MODE 3 for a batch too small to fill the device: wavefronts are to be had, and a short stream is through
+  // the parallel decoder sooner than through the serial pass (85 us against 90 .. 170 us for 128 .. 384 bytes), so it
+  // hands over inputs of under 8 bytes only (SYM 4).
+  constexpr int  SYM  = (MODE == 1 || MODE == 4) ? 1 : MODE == 3 ? 2 : MODE == 5 ? 3 : MODE == 6 ? 4 : 0;
+  static_assert((MODE != 3 && MODE != 5 && MODE != 6) || T == 64, "the parallel block decoder uses the whole wavefront");
   __shared__ StreamLds<F> lds[G];
   ParLds   *parp = nullptr;
   uint32_t *note = nullptr;
-  if constexpr (MODE == 3 || MODE == 5) {
+  if constexpr (MODE == 3 || MODE == 5 || MODE == 6) {
     __shared__ ParLds par;
     parp = &par;
   }
@@ -2245,13 +2253,13 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5) ? 4 : 1) void infl_bat
     }
     return;
   }
-  if ((MODE == 1 || MODE == 3 || MODE == 4) && rc != INFL_D_OK) {
+  if ((MODE == 1 || MODE == 3 || MODE == 4 || MODE == 6) && rc != INFL_D_OK) {
     // The parallel pass reports a stream that certainly fails by itself when the caller wants
     // the reference's result only (UNZ_ERR and the output position infl() leaves, which does not
     // depend on why or where the stream failed); the reason, the input position and the
     // position reached are worked out by the serial passes.
     const bool exact = detail != nullptr || inpos != nullptr || (flags & INFL_F_PROGRESS);
-    const bool undecided = MODE != 3 || rc == INFL_D_NOFIT || rc == INFL_D_INTERNAL;
+    const bool undecided = (MODE != 3 && MODE != 6) || rc == INFL_D_NOFIT || rc == INFL_D_INTERNAL;
     if (undecided || exact) {
       if (lig == 0) status[i] = undecided ? INFL_STATUS_DEFERRED : INFL_STATUS_DEFERRED_FAILING;
       return;
@@ -2342,6 +2350,23 @@ __global__ __launch_bounds__(64, 1) void infl_deferred_window_kernel(const uint8
     }
   }
 }
+
+#ifdef DEFL_SMALL_BATCH_UNIT
+}  // namespace defl
+
+// This unit holds the parallel pass for batches too small to fill the device (MODE 6) and nothing else.  It is
+// compiled apart from the other kernels because a second instantiation of the parallel kernel beside the first changes
+// how the compiler treats the functions both call, and the first one's loops, which sit at the register limit, came
+// out 0.5 % slower on the headline batch.
+extern "C" int infl_launch_parallel_small(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
+                                          int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
+                                          uint32_t *inpos, void *mirror, void *stream, const uint32_t *skip) {
+  hipLaunchKernelGGL((defl::infl_batch_kernel<64, defl::CompactFmt, 6>), dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream,
+                     (const uint8_t *)src, src_off, (uint8_t *)dst, dst_off, flags, n, status, outlen, detail, inpos,
+                     (uint8_t *)mirror, skip);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#else
 
 // ---------------------------------------------------------------------------
 // Incremental decode of ONE stream (infl_stream(), reference src/infl/stream.c:468-794): the
@@ -2996,6 +3021,12 @@ __global__ __launch_bounds__(64) void infl_png_unfilter_kernel(const uint8_t *in
 #define DEFL_LAUNCH_GROUP(T)     // (the test suite's host-side emulation is told the lanes per stream of a launch here)
 #endif
 
+#ifndef DEFL_SINGLE_UNIT
+extern "C" int infl_launch_parallel_small(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
+                                          int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
+                                          uint32_t *inpos, void *mirror, void *stream, const uint32_t *skip);
+#endif
+
 // variant 0: reference-geometry tables only (one launch).
 // variant 1: compact tables first, reference-geometry tables for what they defer (two launches).
 // variant 2: wavefront-parallel block decode first (one wavefront per stream); what it defers
@@ -3019,6 +3050,16 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
                        dim3((unsigned)((n + (64 / T) - 1) / (64 / T))), dim3(64), 0, st, s, src_off, \
                        d, dst_off, flags, n, status, outlen, detail, inpos, m, skip);            \
   } while (0)
+#ifdef DEFL_SINGLE_UNIT            /* (the test suite's host-side emulation compiles everything as one unit) */
+#define LAUNCH_SMALL() LAUNCH(64, CompactFmt, 6)
+#else
+#define LAUNCH_SMALL()                                                                                          \
+  do {                                                                                                          \
+    if (infl_launch_parallel_small(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, mirror, \
+                                   stream, skip) != 0)                                                          \
+      return -1;                                                                                                \
+  } while (0)
+#endif
 #define LAUNCH_DEFERRED_PLAIN(T) LAUNCH(T, CompactFmt, 4)
 #define LAUNCH_DEFERRED_WINDOW(T)                                                                              \
   do {                                                                                                         \
@@ -3035,7 +3076,11 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
     LAUNCH(T, CompactFmt, 1);   \
     LAUNCH(T, RefFmt, 2);       \
   } else {                      \
-    LAUNCH(64, CompactFmt, 3);  \
+    if (n >= defl::PAR_SHORT_BATCH) { \
+      LAUNCH(64, CompactFmt, 3); \
+    } else {                    \
+      LAUNCH_SMALL();           \
+    }                           \
     if (variant == 2 || variant == 4) { \
       DEFERRED(T);              \
     }                           \
@@ -3055,6 +3100,7 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
   }
 #undef LAUNCH_T
 #undef LAUNCH_DEFERRED_WINDOW
+#undef LAUNCH_SMALL
 #undef LAUNCH_DEFERRED_PLAIN
 #undef LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -3123,3 +3169,5 @@ extern "C" __attribute__((visibility("default"))) int infl_debug_par_profile(uns
   return hipMemcpyToSymbol(HIP_SYMBOL(defl::g_par_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+#endif  // DEFL_SMALL_BATCH_UNIT

@@ -524,3 +524,19 @@ def test_short_streams_among_long_ones(engine, oracle, lanes):
     streams, caps = streams[:20003], caps[:20003]
     status, _, _ = _check_batch(engine, oracle, streams, caps, 1, lanes, "short among long", 2)
     assert (status == 0).sum() > 15000 and (status != 0).sum() > 500
+
+
+@pytest.mark.parametrize("n", [6143, 6144])
+def test_short_streams_either_side_of_the_batch_size_that_routes_them(engine, oracle, n):
+    """Batches of under 6144 streams keep short streams in the parallel pass (its other instantiation), larger ones
+    leave them to the serial pass: same results either side."""
+    rng = random.Random(n)
+    base = [(r, wl.deflate(r)) for r in (wl.text_stream(9500 + i, rng.choice([0, 3, 90, 200, 350, 500, 900])) for i in range(64))]
+    streams, caps = [], []
+    for i in range(n):
+        raw, c = base[rng.randrange(64)]
+        if i % 97 == 5 and len(c) > 6:
+            c = c[: len(c) // 2]
+        streams.append(c); caps.append(len(raw) if i % 89 else max(0, len(raw) - 7))
+    status, _, _ = _check_batch(engine, oracle, streams, caps, 1, 16, "batch of %d" % n, 2)
+    assert (status == 0).sum() > n * 0.9 and (status != 0).sum() > 20
