@@ -24,7 +24,7 @@ EXPORTS = [
     "infl_gpu_init", "infl_gpu_device_count", "infl_batch_dev", "infl_batch_dev_detail", "infl_batch",
     "infl_many", "infl_gpu_malloc", "infl_gpu_free", "infl_gpu_upload", "infl_gpu_download",
     "infl_gpu_sync", "infl_gpu_set_lanes_per_stream", "infl_gpu_set_table_variant",
-    "infl_batch_noalloc", "infl_batch_dev_checked", "infl_batch_checked", "infl_png_unfilter_dev",
+    "infl_batch_noalloc", "infl_batch_dev_checked", "infl_batch_checked", "infl_png_unfilter_dev", "infl_gather_dev",
 ]
 
 
@@ -126,6 +126,7 @@ class Engine:
             "infl_batch_dev_checked": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp, vp, vp]),
             "infl_batch_checked": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp]),
             "infl_png_unfilter_dev": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]),
+            "infl_gather_dev": (i32, [vp, vp, vp, vp, sz, vp, vp]),
             "infl_many": (i32, [vp, sz, vp]),
             "infl_gpu_malloc": (vp, [sz]),
             "infl_gpu_free": (None, [vp]),
@@ -184,6 +185,30 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"infl_batch_checked failed: {rc}")
         return dst, status[:n], outlen[:n], detail[:n]
+
+    def gather_into(self, batch: "DeviceBatch", blob, piece_off, piece_len, piece_dst):
+        """infl_gather_dev(): uploads `blob` and the three piece tables and gathers the pieces into the source arena of
+        `batch` (whose src_off must describe the gathered streams).  Enqueues and synchronises."""
+        lib = self.lib
+        blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8))
+        po = np.ascontiguousarray(piece_off, dtype=np.uint64)
+        pl = np.ascontiguousarray(piece_len, dtype=np.uint32)
+        pd = np.ascontiguousarray(piece_dst, dtype=np.uint64)
+        n = len(po)
+        bufs = [lib.infl_gpu_malloc(max(16, a.nbytes + 16)) for a in (blob, po, pl, pd)]
+        try:
+            if not all(bufs):
+                raise MemoryError("infl_gpu_malloc failed")
+            for b, a in zip(bufs, (blob, po, pl, pd)):
+                if a.nbytes:
+                    assert lib.infl_gpu_upload(b, a.ctypes.data, a.nbytes) == 0
+            if lib.infl_gather_dev(bufs[0], bufs[1], bufs[2], bufs[3], n, batch.d_src, None) != 0:
+                raise RuntimeError("infl_gather_dev failed to launch")
+            assert lib.infl_gpu_sync() == 0
+        finally:
+            for b in bufs:
+                if b:
+                    lib.infl_gpu_free(b)
 
     def png_unfilter(self, batch: "DeviceBatch", geom, chained=True):
         """infl_png_unfilter_dev() behind a decoded DeviceBatch: image i is the output of stream i, geom a list

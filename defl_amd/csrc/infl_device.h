@@ -101,6 +101,9 @@ int infl_launch_png_unfilter(const void *in, const uint64_t *in_off, const uint3
                              const int32_t *in_status, void *out, const uint64_t *out_off,
                              const InflPngGeom *geom, uint64_t n, int32_t *status, void *stream);
 
+int infl_launch_gather(const void *blob, const uint64_t *piece_off, const uint32_t *piece_len,
+                       const uint64_t *piece_dst, uint64_t n_pieces, void *out, void *stream);
+
 /* A pinned host buffer for gathering many streams' input before infl_rt_batch_host() (copies
    from pinned memory run at the full link rate).  One buffer per process: returns NULL when it is
    in use, when no device is usable or when pinning fails; the caller then uses ordinary memory.

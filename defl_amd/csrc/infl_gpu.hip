@@ -244,6 +244,13 @@ int infl_png_unfilter_dev(const void *dev_in, const uint64_t *dev_in_off, const 
                                   dev_status, hip_stream);
 }
 
+int infl_gather_dev(const void *dev_blob, const uint64_t *dev_piece_off, const uint32_t *dev_piece_len,
+                    const uint64_t *dev_piece_dst, size_t n_pieces, void *dev_src, void *hip_stream) {
+  if (n_pieces == 0) return 0;
+  if (!dev_blob || !dev_piece_off || !dev_piece_len || !dev_piece_dst || !dev_src) return -1;
+  return infl_launch_gather(dev_blob, dev_piece_off, dev_piece_len, dev_piece_dst, n_pieces, dev_src, hip_stream);
+}
+
 static Buf  g_pin;                 // see infl_rt_pinned_acquire
 static bool g_pin_busy = false;
 static std::mutex g_pin_mu;

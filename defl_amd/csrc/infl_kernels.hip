@@ -3015,6 +3015,31 @@ __global__ __launch_bounds__(64) void infl_png_unfilter_kernel(const uint8_t *in
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gather of input pieces that already lie in device memory (the device-side counterpart of a run of
+// infl_include() calls, reference src/infl/mem.c:114-216: every call appends one byte range to the stream's
+// logical input).  Piece p is blob[piece_off[p] .. + piece_len[p]) and goes to out[piece_dst[p] ..): the
+// caller lays the pieces of a stream one behind the other and the streams into one arena.  One wavefront
+// per piece; a lane moves 16 bytes per access at whatever alignment source and target have (neighbouring
+// lanes, neighbouring bytes), the last bytes of a piece go one at a time.  Bounds are the caller's: the
+// launcher has no way to know how large the blob and the arena are.
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((packed)) Bytes16 { uint32_t w[4]; };          // 16 bytes at any address
+__global__ __launch_bounds__(64) void infl_gather_kernel(const uint8_t *__restrict__ blob,
+                                                         const uint64_t *__restrict__ piece_off,
+                                                         const uint32_t *__restrict__ piece_len,
+                                                         const uint64_t *__restrict__ piece_dst, uint64_t n_pieces,
+                                                         uint8_t *__restrict__ out) {
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t p = blockIdx.x; p < n_pieces; p += gridDim.x) {
+    const uint8_t *s   = blob + piece_off[p];
+    uint8_t       *d   = out + piece_dst[p];
+    const uint32_t len = piece_len[p], body = len & ~15u;
+    for (uint32_t k = 16u * lane; k < body; k += 1024u) *(Bytes16 *)(d + k) = *(const Bytes16 *)(s + k);
+    if (lane < len - body) d[body + lane] = s[body + lane];
+  }
+}
+
 }  // namespace defl
 
 #ifndef DEFL_LAUNCH_GROUP
@@ -3157,6 +3182,17 @@ extern "C" int infl_launch_png_unfilter(const void *in, const uint64_t *in_off, 
   const unsigned grid = n < slots ? (unsigned)n : slots;
   hipLaunchKernelGGL(defl::infl_png_unfilter_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream,
                      (const uint8_t *)in, in_off, in_len, in_status, (uint8_t *)out, out_off, geom, n, status);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int infl_launch_gather(const void *blob, const uint64_t *piece_off, const uint32_t *piece_len,
+                                  const uint64_t *piece_dst, uint64_t n_pieces, void *out, void *stream) {
+  if (n_pieces == 0) return 0;
+  // pieces are a few bytes to a few KiB each: a grid of at most 64 Ki workgroups that take the pieces in turn
+  const unsigned grid = n_pieces < 65536u ? (unsigned)n_pieces : 65536u;
+  DEFL_LAUNCH_GROUP(64);
+  hipLaunchKernelGGL(defl::infl_gather_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)blob,
+                     piece_off, piece_len, piece_dst, n_pieces, (uint8_t *)out);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -136,6 +136,23 @@ infl_png_unfilter_dev(const void *dev_in, const uint64_t *dev_in_off,
                       int32_t *dev_status, void *hip_stream);
 
 /*
+ * infl_include() for input that already lies in device memory (a PNG file uploaded whole, its IDAT
+ * payloads scattered through it): the device-side counterpart of a run of infl_include() calls, each of
+ * which appends one byte range to a stream's logical input (reference src/infl/mem.c:114-216; the
+ * README's PNG loop, README.md:120-155).  Piece p is the dev_piece_len[p] bytes at dev_blob +
+ * dev_piece_off[p] and is copied to dev_src + dev_piece_dst[p]; the caller, who walked the chunk
+ * headers, lays the pieces of a stream one behind the other and the streams one behind the other, and
+ * passes dev_src with the matching dev_src_off to infl_batch_dev().  Pieces of any length (0 included)
+ * at any alignment; dev_src must not overlap the pieces it is gathered from.  No bounds are known to
+ * the call: offsets and lengths must lie inside the caller's buffers.  Enqueues on hip_stream and
+ * returns; 0, or -1 for a NULL argument or a launch that failed.
+ */
+UNZ_EXPORT int
+infl_gather_dev(const void *dev_blob, const uint64_t *dev_piece_off,
+                const uint32_t *dev_piece_len, const uint64_t *dev_piece_dst,
+                size_t n_pieces, void *dev_src, void *hip_stream);
+
+/*
  * infl_batch() for callers that cannot allocate: tight serving loops, harnesses that forbid
  * hipMalloc, code that runs while a HIP graph is being captured elsewhere in the process.  It has
  * no counterpart in the reference.  Same arguments and results as infl_batch(), but the device

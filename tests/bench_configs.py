@@ -9,7 +9,7 @@ oracle before a number is printed.
   png      4 096 PNG-like images (128x128 RGBA scanlines, zlib-6) fed as IDAT pieces with
            infl_include() and decoded with one infl_many() call (host path, PCIe inclusive)
   mixed    text streams with log-uniform sizes 1 KiB .. 256 KiB, sorted by size (config 5 shape)
-  runs, textruns, truncated, flushed, small, tiny, files, noisy, pngdev, host
+  runs, textruns, truncated, flushed, small, tiny, files, noisy, pngdev, gather, host
            what real batches hold besides clean text: byte runs, text with runs spliced in, a
            damaged stream in 64, flush points every few bytes, streams of 1 / 4 / 16 KiB, slices of
            local binaries and scripts, near fixed-length codes, PNG-like scanlines kept on the
@@ -74,7 +74,7 @@ def run_device(eng, oracle, comps, raws_len, flags, reps, tile, steps=5, failing
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,truncated,flushed,small,tiny,files,noisy,pngdev,host,png")
+    ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,truncated,flushed,small,tiny,files,noisy,pngdev,gather,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
     args = ap.parse_args()
@@ -206,6 +206,54 @@ def main():
         r = run_device(eng, oracle, comps, [len(x) for x in raws], 1, 5, int(128 * args.scale))
         print(json.dumps({"config": "PNG-like scanlines, device resident (ratio %.3f)"
                                     % (sum(map(len, comps)) / float(sum(map(len, raws)))), **r}), flush=True)
+    if "gather" in which:
+        # the IDAT configuration with the files already on the device: the IDAT payloads (11.5 pieces per image, 12
+        # bytes of chunk header and CRC between them) are gathered into one arena, which is then decoded
+        raws = [wl.png_like(i) for i in range(256)]
+        comps = [wl.deflate(x) for x in raws]
+        tile = int(16 * args.scale)
+        blob, po, pl, pd, so, caps = bytearray(), [], [], [], [0], []
+        for t in range(tile):
+            for i, c in enumerate(comps):
+                at = so[-1]
+                for piece in wl.idat_pieces(i + 256 * t, c):
+                    blob += b"\0" * 12
+                    po.append(len(blob)); pl.append(len(piece)); pd.append(at)
+                    blob += piece; at += len(piece)
+                so.append(at); caps.append(len(raws[i]))
+        n = len(caps)
+        do = np.concatenate([[0], np.cumsum(caps)]).astype(np.uint64)
+        b = eng.device_batch(np.zeros(so[-1], dtype=np.uint8), np.array(so, dtype=np.uint64), do)
+        lib = eng.lib
+        arrs = [np.frombuffer(bytes(blob), dtype=np.uint8), np.array(po, dtype=np.uint64), np.array(pl, dtype=np.uint32),
+                np.array(pd, dtype=np.uint64)]
+        dev = [lib.infl_gpu_malloc(a.nbytes + 16) for a in arrs]
+        assert all(dev)
+        for d, a in zip(dev, arrs):
+            assert lib.infl_gpu_upload(d, a.ctypes.data, a.nbytes) == 0
+        def gather():
+            assert lib.infl_gather_dev(dev[0], dev[1], dev[2], dev[3], len(po), b.d_src, None) == 0
+        gather(); b.run(1, detail=False)
+        dst, status, outlen, _ = b.results()
+        assert (status == 0).all()
+        for i in (0, 1, n // 2, n - 1):
+            assert dst[int(do[i]):int(do[i + 1])].tobytes() == raws[i % 256]
+        times = {}
+        for name, fn in (("gather", gather), ("gather + decode", lambda: (gather(), b.run(1, detail=False)))):
+            assert lib.infl_gpu_sync() == 0
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            assert lib.infl_gpu_sync() == 0
+            times[name] = (time.perf_counter() - t0) / 20
+        for d in dev:
+            lib.infl_gpu_free(d)
+        b.free()
+        print(json.dumps({"config": "PNG IDAT pieces gathered on the device (infl_gather_dev), then decoded", "streams": n,
+                          "pieces": len(po), "gathered_bytes": int(so[-1]), "gather_ms": round(times["gather"] * 1e3, 3),
+                          "gather_GB_per_s_read_plus_written": round(2 * so[-1] / times["gather"] / 1e9, 1),
+                          "gather_plus_decode_ms": round(times["gather + decode"] * 1e3, 3),
+                          "out_bytes": int(do[-1])}), flush=True)
     if "host" in which:
         # host arenas through infl_batch(): upload, three launches, download (PCIe inclusive)
         n = int(16384 * args.scale)

@@ -288,6 +288,32 @@ static int main_png(char **argv) {
   return 0;
 }
 
+// emu_run <in.bin> <out.bin> gather 0 0: the device-side gather of input pieces.
+//   in : u64 n_pieces, u64 blob_len, u64 out_len, u64 piece_off[n], u64 piece_dst[n], u32 piece_len[n], blob bytes
+//   out: the gathered arena (out_len bytes, 0xee where nothing was written)
+// Blob and arena have their exact sizes, so that AddressSanitizer sees any access outside them.
+static int main_gather(char **argv) {
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  uint64_t hdr[3];
+  if (fread(hdr, 8, 3, f) != 3) return 2;
+  const uint64_t n = hdr[0], blob_len = hdr[1], out_len = hdr[2];
+  std::vector<uint64_t> off(n + 1), dst(n + 1);
+  std::vector<uint32_t> len(n + 1);
+  if (n && (fread(off.data(), 8, n, f) != n || fread(dst.data(), 8, n, f) != n || fread(len.data(), 4, n, f) != n)) return 2;
+  uint8_t *blob = (uint8_t *)malloc(blob_len ? blob_len : 1), *out = (uint8_t *)malloc(out_len ? out_len : 1);
+  if (blob_len && fread(blob, 1, blob_len, f) != blob_len) return 2;
+  fclose(f);
+  memset(out, 0xee, out_len ? out_len : 1);
+  if (infl_launch_gather(blob, off.data(), len.data(), dst.data(), n, out, nullptr) != 0) return 3;
+  f = fopen(argv[2], "wb");
+  fwrite(out, 1, out_len, f);
+  fclose(f);
+  free(blob);
+  free(out);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 6) return 2;
   // Between two barriers the lanes run one after the other; in which order must not matter to a correct kernel.
@@ -295,6 +321,7 @@ int main(int argc, char **argv) {
   if (order && !strcmp(order, "reverse")) emu::g_dir = -1;
   if (!strcmp(argv[3], "resume")) return main_resume(argc, argv);
   if (!strcmp(argv[3], "png")) return main_png(argv);
+  if (!strcmp(argv[3], "gather")) return main_gather(argv);
   FILE *f = fopen(argv[1], "rb");
   if (!f) return 2;
   uint64_t n = 0;

@@ -90,3 +90,21 @@ def run_png(filtered, geom, in_len=None, in_status=None, timeout=900):
     status = np.frombuffer(raw, dtype=np.int32, count=n, offset=0)
     out = raw[4 * n:]
     return [out[int(oo[i]):int(oo[i + 1])] for i in range(n)], status
+
+
+def run_gather(blob, piece_off, piece_len, piece_dst, out_len, timeout=600):
+    """infl_gather_kernel in the emulator: -> the gathered arena (uint8, 0xee where nothing was written)."""
+    n = len(piece_off)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([n, len(blob), out_len], dtype=np.uint64).tobytes())
+            f.write(np.asarray(piece_off, dtype=np.uint64).tobytes())
+            f.write(np.asarray(piece_dst, dtype=np.uint64).tobytes())
+            f.write(np.asarray(piece_len, dtype=np.uint32).tobytes())
+            f.write(bytes(blob))
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0")
+        p = subprocess.run([EXE, fin, fout, "gather", "0", "0"], capture_output=True, timeout=timeout, env=env)
+        if p.returncode != 0:
+            raise RuntimeError("emu_run gather failed (%d): %s" % (p.returncode, p.stderr.decode()[-2000:]))
+        return np.fromfile(fout, dtype=np.uint8)

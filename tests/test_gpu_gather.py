@@ -1,0 +1,84 @@
+"""Device-side gather of input pieces (infl_gather_dev): what a run of infl_include() calls does to a stream's logical
+input (reference src/infl/mem.c:114-216), for pieces that already lie in device memory.  The expected result is the
+pieces one behind the other (the reference's own chunked tests check exactly that through the decode,
+test/test_files.c:1091-1103); the decode behind it is compared with the CPU oracle."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import random
+
+import workloads as wl
+from tests import oracle_lib
+from tests.test_kernel_emulation import _pieces_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pieces_of_every_length_and_alignment(engine):
+    assert engine.lib.infl_gpu_init(0) == 0
+    rng = random.Random(78)
+    blob, po, pl, pd, so, streams = _pieces_case(rng, 300, [0, 1, 5, 16, 31, 100, 1024, 4097, 9000, 70000])
+    n = len(streams)
+    src0 = np.full(so[-1], 0xEE, dtype=np.uint8)                       # the arena before the gather
+    b = engine.device_batch(src0, np.array(so, dtype=np.uint64), np.zeros(n + 1, dtype=np.uint64))
+    try:
+        engine.gather_into(b, blob, po, pl, pd)
+        got = np.zeros(max(1, so[-1]), dtype=np.uint8)
+        assert engine.lib.infl_gpu_download(got.ctypes.data, b.d_src, so[-1]) == 0
+    finally:
+        b.free()
+    assert got[:so[-1]].tobytes() == b"".join(streams)
+    assert engine.lib.infl_gather_dev(None, None, None, None, 0, None, None) == 0      # nothing to do
+    assert engine.lib.infl_gather_dev(None, None, None, None, 5, None, None) == -1
+
+
+def _png_file(i, width, height, bpp):
+    """A PNG-shaped container (signature, IHDR, IDAT chunks of seeded sizes, IEND; CRCs as the format has them) around
+    one image: -> file bytes, (offset, length) of every IDAT payload, the pixels, the geometry."""
+    pixels, filtered, _ = wl.png_filtered(i, width, height, bpp)
+    comp = wl.deflate(filtered)
+    out = bytearray(b"\x89PNG\r\n\x1a\n")
+
+    def chunk(kind, body):
+        at = len(out) + 8
+        out.extend(struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body)))
+        return at
+    chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 6, 0, 0, 0))
+    spans = [(chunk(b"IDAT", p), len(p)) for p in wl.idat_pieces(i, comp)]
+    chunk(b"IEND", b"")
+    return bytes(out), spans, pixels, filtered, (height, width * bpp, bpp)
+
+
+def test_png_files_uploaded_whole_gather_inflate_unfilter(engine):
+    """The README's PNG loop (reference README.md:120-155) with everything after the upload on the device: the files
+    go up as they are, the IDAT payloads are gathered into one arena, decoded in one batch and un-filtered."""
+    assert engine.lib.infl_gpu_init(0) == 0
+    oracle = oracle_lib.load()
+    blob, po, pl, pd, so, caps, geom, want_px, want_f = bytearray(), [], [], [], [0], [], [], [], []
+    for i in range(96):
+        w, h, bpp = [(128, 128, 4), (33, 17, 3), (200, 5, 1), (64, 64, 8)][i % 4]
+        f, spans, pixels, filtered, g = _png_file(900 + i, w, h, bpp)
+        at = so[-1]
+        for off, ln in spans:
+            po.append(len(blob) + off); pl.append(ln); pd.append(at); at += ln
+        blob += f
+        so.append(at); caps.append(len(filtered)); geom.append(g); want_px.append(pixels); want_f.append(filtered)
+    n = len(caps)
+    assert len(po) > 2 * n                                              # several pieces per image
+    do = np.concatenate([[0], np.cumsum(caps)]).astype(np.uint64)
+    b = engine.device_batch(np.zeros(so[-1], dtype=np.uint8), np.array(so, dtype=np.uint64), do)
+    try:
+        engine.gather_into(b, blob, po, pl, pd)
+        b.run(flags=1)
+        dst, status, outlen, _ = b.results()
+        out, st = engine.png_unfilter(b, geom)
+    finally:
+        b.free()
+    assert (status == 0).all() and (outlen == np.array(caps)).all()
+    for i in range(n):
+        a = int(do[i])
+        assert dst[a:a + caps[i]].tobytes() == want_f[i], i
+        assert oracle.png_unfilter(want_f[i], *geom[i]) == (0, want_px[i])
+        assert st[i] == 0 and out[i] == want_px[i], i

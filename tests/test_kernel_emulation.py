@@ -429,3 +429,39 @@ def test_emulated_short_streams_share_wavefronts(oracle, lanes):
             assert st4[i] == 0x40000003, (i, hex(int(st4[i])))
         elif len(c) >= 256 and status[i] == 0:
             assert st4[i] == 0, (i, hex(int(st4[i])))
+
+
+def _pieces_case(rng, n_streams, sizes):
+    """Streams cut into pieces that lie scattered through a blob (a chunked container): -> blob, piece_off, piece_len,
+    piece_dst, src_off, the streams."""
+    streams = [bytes(rng.randrange(256) for _ in range(rng.choice(sizes))) for _ in range(n_streams)]
+    blob, piece_off, piece_len, piece_dst, src_off = bytearray(), [], [], [], [0]
+    at = 0
+    for s in streams:
+        k = 0
+        while k < len(s) or (not s and k == 0):
+            n = min(len(s) - k, rng.choice([0, 1, 2, 15, 16, 17, 63, 100, 1023, 1024, 1025, 3000]))
+            blob += bytes(rng.randrange(256) for _ in range(rng.randrange(0, 13)))        # chunk headers, CRCs, other chunks
+            piece_off.append(len(blob)); piece_len.append(n); piece_dst.append(at + k)
+            blob += s[k:k + n]
+            k += n
+            if not s:
+                break
+        at += len(s)
+        src_off.append(at)
+    blob += bytes(rng.randrange(256) for _ in range(5))
+    return bytes(blob), piece_off, piece_len, piece_dst, src_off, streams
+
+
+def test_emulated_gather_of_pieces():
+    """infl_gather_kernel: pieces of every length and alignment end up where infl_include() calls in the same order would
+    put them (one behind the other per stream); nothing outside blob and arena is touched (exact-size buffers, ASan)."""
+    rng = random.Random(77)
+    blob, po, pl, pd, so, streams = _pieces_case(rng, 40, [0, 1, 5, 16, 31, 100, 1024, 4097, 9000])
+    out = emu_lib.run_gather(blob, po, pl, pd, so[-1])
+    assert out.tobytes() == b"".join(streams)
+    assert emu_lib.run_gather(b"", [], [], [], 0).size == 0
+    # pieces that leave gaps in the arena: the gaps stay as they were
+    out = emu_lib.run_gather(bytes(range(200)), [3, 50], [20, 17], [1, 40], 64)
+    want = bytearray(b"\xee" * 64); want[1:21] = bytes(range(3, 23)); want[40:57] = bytes(range(50, 67))
+    assert out.tobytes() == bytes(want)
