@@ -202,7 +202,7 @@ int infl_gpu_set_table_variant(int variant) {
 #else
   constexpr int kMaxVariant = 2;
 #endif
-  if (variant >= 0 && variant <= kMaxVariant) g_variant.store(variant);
+  if ((variant >= 0 && variant <= kMaxVariant) || variant == 5) g_variant.store(variant);
   return g_variant.load();
 }
 

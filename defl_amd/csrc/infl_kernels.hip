@@ -2368,6 +2368,12 @@ extern "C" int infl_launch_parallel_small(const void *src, const uint64_t *src_o
 }
 #else
 
+// Marks every stream for the serial passes (variant 5 of infl_launch_batch: those passes alone).
+__global__ __launch_bounds__(256) void infl_mark_kernel(int32_t *__restrict__ status, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i < n) status[i] = INFL_STATUS_DEFERRED;
+}
+
 // ---------------------------------------------------------------------------
 // Incremental decode of ONE stream (infl_stream(), reference src/infl/stream.c:468-794): the
 // input seen so far is decoded from where the last call stopped, symbol by symbol, by one
@@ -3059,6 +3065,8 @@ extern "C" int infl_launch_parallel_small(const void *src, const uint64_t *src_o
 //            tiny streams) goes through the two serial passes of variant 1 (three launches).
 // variant 3: diagnostic: the parallel pass alone; deferred streams keep INFL_STATUS_DEFERRED.
 // variant 4: diagnostic: the parallel pass and the serial pass behind it; what they leave keeps its mark.
+// variant 5: the two serial passes of variant 2 alone, for every stream (variant 1 with the second pass's own kernel
+//            for 8 and 16 lanes per stream, which shares a window's marked streams out among its wavefronts).
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                                  uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
@@ -3099,6 +3107,11 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
     LAUNCH(T, RefFmt, 0);       \
   } else if (variant == 1) {    \
     LAUNCH(T, CompactFmt, 1);   \
+    LAUNCH(T, RefFmt, 2);       \
+  } else if (variant == 5) {    \
+    DEFL_LAUNCH_GROUP(64);      \
+    hipLaunchKernelGGL(defl::infl_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, status, n); \
+    DEFERRED(T);                \
     LAUNCH(T, RefFmt, 2);       \
   } else {                      \
     if (n >= defl::PAR_SHORT_BATCH) { \

@@ -20,7 +20,7 @@ DATA = os.path.join(HERE, "golden", "defl_testdata")
 ALL = sorted(os.listdir(os.path.join(DATA, "compressed")))
 PAIRS = [f for f in ALL if os.path.exists(os.path.join(DATA, "raw", f))]
 DEFAULT_VARIANT = 2
-VARIANTS = [(64, 0), (32, 0), (16, 0), (8, 0), (64, 1), (32, 1), (16, 1), (8, 1), (16, 2), (64, 2)]
+VARIANTS = [(64, 0), (32, 0), (16, 0), (8, 0), (64, 1), (32, 1), (16, 1), (8, 1), (16, 2), (64, 2), (16, 5), (8, 5)]
 
 
 def _read(kind, name):
@@ -146,7 +146,7 @@ def test_zlib_streams_batch(engine, oracle, wrap, lanes, variant):
             assert status[i] == -1 and detail[i] == capi.D_FULL
 
 
-@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (64, 1), (16, 1), (8, 1), (16, 2)])
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (64, 1), (16, 1), (8, 1), (16, 2), (16, 5), (8, 5)])
 def test_fuzz_mutations_and_truncations(engine, oracle, lanes, variant):
     """Differential fuzz against the oracle on malformed input: flipped bits, truncation,
     random bytes.  Return code, output position and bytes must match stream by stream."""

@@ -42,7 +42,7 @@ def _compare(oracle, streams, caps, flags, lanes, variant=0, plain=False):
     return status, outlen, detail
 
 
-@pytest.mark.parametrize("lanes,variant", [(64, 0), (8, 0), (16, 1), (32, 1), (64, 2), (16, 2)])
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (8, 0), (16, 1), (32, 1), (64, 2), (16, 2), (16, 5), (8, 5)])
 def test_emulated_kernel_on_fixtures(oracle, lanes, variant):
     names = list(ALL)
     streams = [_read("compressed", n) for n in names]
@@ -54,7 +54,7 @@ def test_emulated_kernel_on_fixtures(oracle, lanes, variant):
             assert s == 0, n
 
 
-@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (8, 1), (64, 2)])
+@pytest.mark.parametrize("lanes,variant", [(64, 0), (16, 0), (8, 1), (64, 2), (16, 5)])
 def test_emulated_kernel_on_header_cases(oracle, lanes, variant):
     streams = header_cases()
     _compare(oracle, streams, [4096] * len(streams), 0, lanes, variant)
@@ -68,6 +68,8 @@ def test_emulated_kernel_zlib_and_fuzz(oracle):
     caps = [len(r) for r in raws for _ in range(3)]
     _compare(oracle, good, caps, 1, 32)
     _compare(oracle, good, caps, 1, 16, 1)
+    _compare(oracle, good, caps, 1, 16, 5)
+    _compare(oracle, good, caps, 1, 8, 5)
     _compare(oracle, good, caps, 1, 64, 2)
     _compare(oracle, good, [max(0, c - 1) for c in caps], 1, 64, 2)
     _compare(oracle, good, [max(0, c - 1) for c in caps], 1, 64)
@@ -84,6 +86,7 @@ def test_emulated_kernel_zlib_and_fuzz(oracle):
     _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 32)
     _compare(oracle, bad, [8000] * len(bad), 0, 8)
     _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 8, 1)
+    _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 16, 5)
     _compare(oracle, bad, [rng.choice([0, 100, 8000]) for _ in bad], 1, 64, 2)
 
 
@@ -465,3 +468,31 @@ def test_emulated_gather_of_pieces():
     out = emu_lib.run_gather(bytes(range(200)), [3, 50], [20, 17], [1, 40], 64)
     want = bytearray(b"\xee" * 64); want[1:21] = bytes(range(3, 23)); want[40:57] = bytes(range(50, 67))
     assert out.tobytes() == bytes(want)
+
+
+def test_emulated_serial_passes_alone_match_shapes(oracle):
+    """Variant 5 = the serial passes alone, the first one through the windowed kernel: matches at distances around 2 KiB,
+    matches that repeat their source (distance < length), runs, stored blocks between Huffman blocks."""
+    rng = random.Random(55)
+    raws = []
+    raws.append(wl.text_stream(1, 9000))                                          
+    raws.append((b"abcdefghij" * 30 + bytes(rng.randrange(256) for _ in range(40))) * 12)   
+    raws.append(bytes(rng.randrange(256) for _ in range(1700)) * 3)               
+    raws.append(bytes(rng.randrange(256) for _ in range(1791)) * 3)               
+    raws.append(bytes(rng.randrange(256) for _ in range(2049)) * 3)               
+    raws.append(b"xy" * 3000 + b"q" * 2500 + b"xyz" * 900)                        # repeating sources, runs
+    raws.append(bytes(5000))
+    raws.append(wl.text_stream(2, 300) + bytes(rng.randrange(256) for _ in range(700)) + wl.text_stream(2, 300) * 4)
+    comps = [wl.deflate(r, lvl) for r in raws for lvl in (1, 6, 9)]
+    caps = [len(r) for r in raws for _ in range(3)]
+    # stored blocks between compressed ones: flush with incompressible bytes in between
+    c = zlib.compressobj(6)
+    parts, mixed = [], b""
+    for k in range(6):
+        piece = wl.text_stream(10 + k, 700) if k % 2 == 0 else bytes(rng.randrange(256) for _ in range(900))
+        mixed += piece
+        parts.append(c.compress(piece) + c.flush(zlib.Z_FULL_FLUSH))
+    comps.append(b"".join(parts) + c.flush()); caps.append(len(mixed))
+    for lanes in (16, 8):
+        _compare(oracle, comps, caps, 1, lanes, 5)
+    _compare(oracle, comps, [max(0, c_ - 5) for c_ in caps], 1, 16, 5)
