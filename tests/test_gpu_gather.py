@@ -34,6 +34,29 @@ def test_pieces_of_every_length_and_alignment(engine):
     assert engine.lib.infl_gather_dev(None, None, None, None, 5, None, None) == -1
 
 
+def test_more_pieces_than_workgroups_and_one_large_piece(engine):
+    """100 000 pieces of 0..40 bytes (the launch has at most 65 536 workgroups, which take the pieces in turn) and one
+    piece of 3 MiB (a wavefront goes through it 1 KiB at a time)."""
+    assert engine.lib.infl_gpu_init(0) == 0
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 41, size=100000).astype(np.uint32)
+    lens[777] = 3 << 20
+    gaps = rng.integers(0, 9, size=lens.size).astype(np.uint64)
+    piece_off = np.cumsum(gaps + np.concatenate([[0], lens[:-1]]).astype(np.uint64)).astype(np.uint64)
+    blob = rng.integers(0, 256, size=int(piece_off[-1] + lens[-1] + 3), dtype=np.uint8)
+    piece_dst = np.concatenate([[0], np.cumsum(lens.astype(np.uint64))[:-1]]).astype(np.uint64)
+    total = int(lens.sum())
+    b = engine.device_batch(np.zeros(total, dtype=np.uint8), np.array([0, total], dtype=np.uint64), np.zeros(2, dtype=np.uint64))
+    try:
+        engine.gather_into(b, blob.tobytes(), piece_off, lens, piece_dst)
+        got = np.zeros(total, dtype=np.uint8)
+        assert engine.lib.infl_gpu_download(got.ctypes.data, b.d_src, total) == 0
+    finally:
+        b.free()
+    want = np.concatenate([blob[int(o):int(o) + int(n)] for o, n in zip(piece_off, lens)])
+    assert np.array_equal(got, want)
+
+
 def _png_file(i, width, height, bpp):
     """A PNG-shaped container (signature, IHDR, IDAT chunks of seeded sizes, IEND; CRCs as the format has them) around
     one image: -> file bytes, (offset, length) of every IDAT payload, the pixels, the geometry."""
