@@ -103,12 +103,16 @@ struct RefFmt {
 };
 
 // ---------------------------------------------------------------------------
-// CompactFmt: 16-bit entries.  bits 0-3 code length (or subtable index bits),
-// bits 4-12 payload, bit 13 SUBTABLE, bit 14 BASE (length / distance symbol),
-// bit 15 LITERAL; END carries only its flag and a length, 0 = no code.
-// A BASE entry stores its value as mantissa and shift, so decode needs no
-// second table: payload bits 0-3 = extra bits x, bits 4-6 = mantissa m, bit 7 =
-// "length 258"; length base = 3 + (m << x), distance base = 1 + (m << x).
+// CompactFmt: 16-bit entries whose class shows in their magnitude, so that the
+// symbol loops tell the classes apart with one unsigned comparison each:
+//   >= 0xC000  SUBTABLE  bits 0-3 index bits, bits 4-12 offset / 2
+//   >= 0x8000  LENGTH    bits 0-4 total = code length + extra bits, 5-8 code length,
+//                        9-11 mantissa m, 12 "length 258"; base = 3 + (m << extra bits)
+//   >= 0x4000  LITERAL   bits 0-4 code length, 5-12 the byte
+//   >= 0x2000  DISTANCE  bits 0-4 total, 5-8 code length, 9-11 mantissa; base = 1 + (m << extra bits)
+//   below      END       bits 0-4 code length; 0 = no code
+// Bits 0-4 are what the code consumes whatever its class.  A base is stored as
+// mantissa and shift, so decode needs no second table.
 // ---------------------------------------------------------------------------
 struct CompactFmt {
   typedef uint16_t entry_t;
@@ -119,50 +123,54 @@ struct CompactFmt {
   // Smaller tables (768 / 320) sent 3 of 8 192 level-6 text streams, whose 15-bit distance codes
   // need 386 entries, to the serial passes, where one stream takes as long as a whole batch.
   static constexpr int LIT_CAP = 856, DIST_CAP = 404;
-  static constexpr uint32_t F_LITERAL = 1u << 15, F_BASE = 1u << 14, F_SUB = 1u << 13, F_END = 1u << 12;
-  static constexpr uint32_t F_L258 = 1u << 11;
+  static constexpr uint32_t C_SUB = 0xC000u, C_LENGTH = 0x8000u, C_LITERAL = 0x4000u, C_DIST = 0x2000u;
+  static constexpr uint32_t F_L258 = 1u << 12;
 
   static __device__ __forceinline__ entry_t lit_entry(uint32_t sym, uint32_t len) {
-    if (sym < 256) return (entry_t)(F_LITERAL | (sym << 4) | len);
-    if (sym == 256) return (entry_t)(F_END | len);
+    if (sym < 256) return (entry_t)(C_LITERAL | (sym << 5) | len);
+    if (sym == 256) return (entry_t)len;
     if (sym > 285) return 0;
     uint32_t i = sym - 257;
-    if (i == 28) return (entry_t)(F_BASE | F_L258 | len);
+    if (i == 28) return (entry_t)(C_LENGTH | F_L258 | (len << 5) | len);
     uint32_t x = i < 8 ? 0u : (i - 4) >> 2;
     uint32_t m = i < 8 ? i : 4 + (i & 3);
-    return (entry_t)(F_BASE | (m << 8) | (x << 4) | len);
+    return (entry_t)(C_LENGTH | (m << 9) | (len << 5) | (len + x));
   }
   static __device__ __forceinline__ entry_t dist_entry(uint32_t sym, uint32_t len) {
     if (sym > 29) return 0;
     uint32_t x = sym < 4 ? 0u : (sym >> 1) - 1;
     uint32_t m = sym < 4 ? sym : 2 + (sym & 1);
-    return (entry_t)(F_BASE | (m << 8) | (x << 4) | len);
+    return (entry_t)(C_DIST | (m << 9) | (len << 5) | (len + x));
   }
   // subtable offsets are even (main table and every subtable have even sizes): at / 2 fits 9 bits
   static __device__ __forceinline__ entry_t sub_entry(uint32_t at, uint32_t bits) {
-    return (entry_t)(F_SUB | ((at >> 1) << 4) | bits);
+    return (entry_t)(C_SUB | ((at >> 1) << 4) | bits);
   }
-  static __device__ __forceinline__ bool is_sub(uint32_t e) { return e & F_SUB; }
+  static __device__ __forceinline__ bool is_sub(uint32_t e) { return e >= C_SUB; }
   static __device__ __forceinline__ uint32_t sub_at(uint32_t e) { return ((e >> 4) & 0x1ffu) << 1; }
   static __device__ __forceinline__ uint32_t sub_bits(uint32_t e) { return e & 15u; }
-  static __device__ __forceinline__ uint32_t xbits(uint32_t e) { return (e >> 4) & 15u; }
+  static __device__ __forceinline__ uint32_t total(uint32_t e) { return e & 31u; }
+  static __device__ __forceinline__ uint32_t codelen(uint32_t e) { return (e >> 5) & 15u; }       // LENGTH, DISTANCE
+  static __device__ __forceinline__ uint32_t xbits(uint32_t e) { return total(e) - codelen(e); }  // LENGTH, DISTANCE
+  static __device__ __forceinline__ uint32_t literal(uint32_t e) { return (e >> 5) & 0xffu; }
   static __device__ __forceinline__ uint32_t len_base(uint32_t e) {
-    return (e & F_L258) ? 258u : 3u + (((e >> 8) & 7u) << xbits(e));
+    return (e & F_L258) ? 258u : 3u + (((e >> 9) & 7u) << xbits(e));
   }
   static __device__ __forceinline__ uint32_t dist_base(uint32_t e) {
-    return 1u + (((e >> 8) & 7u) << xbits(e));
+    return 1u + (((e >> 9) & 7u) << xbits(e));
   }
   static __device__ __forceinline__ Sym lit_sym(uint32_t e) {
     Sym s;
-    s.codelen = e & 15u;
+    s.codelen = total(e);
     s.xbits   = 0;
-    s.base    = (e >> 4) & 0xffu;
-    if (e & F_LITERAL) {
+    s.base    = literal(e);
+    if (e >= C_LENGTH) {
+      s.kind    = K_BASE;
+      s.codelen = codelen(e);
+      s.xbits   = xbits(e);
+      s.base    = len_base(e);
+    } else if (e >= C_LITERAL) {
       s.kind = K_LITERAL;
-    } else if (e & F_BASE) {
-      s.kind  = K_BASE;
-      s.xbits = (e & F_L258) ? 0u : xbits(e);
-      s.base  = len_base(e);
     } else {
       s.kind = e ? K_END : K_INVALID;
     }
@@ -170,7 +178,7 @@ struct CompactFmt {
   }
   static __device__ __forceinline__ Sym dist_sym(uint32_t e) {
     Sym s;
-    s.codelen = e & 15u;
+    s.codelen = codelen(e);
     s.kind    = e ? K_BASE : K_INVALID;
     s.xbits   = xbits(e);
     s.base    = dist_base(e);
@@ -1168,36 +1176,36 @@ __device__ __forceinline__ int huffman_block_compact(FastReader<T> &r, uint8_t *
     rd_fill(r);
     uint32_t b = (uint32_t)r.bits;
     uint32_t e = lit[b & ((1u << F::LIT_BITS) - 1u)];
-    if (e & F::F_SUB) e = lit[F::sub_at(e) + ((b >> F::LIT_BITS) & ((1u << (e & 15u)) - 1u))];
-    uint32_t cl = e & 15u;
-    if (e & F::F_LITERAL) {
-      if (pos >= cap) break;
-      rd_drop(r, cl);
-      if (lig == 0) dst[pos] = (uint8_t)(e >> 4);
-      last       = (e >> 4) & 0xffu;
-      last_known = true;
-      pos++;
-      continue;
-    }
-    if (!(e & F::F_BASE)) {                        // end of block, or no code
-      if (e) {
-        rd_drop(r, cl);
+    if (F::is_sub(e)) e = lit[F::sub_at(e) + ((b >> F::LIT_BITS) & ((1u << F::sub_bits(e)) - 1u))];
+    if (e < F::C_LENGTH) {
+      if (e >= F::C_LITERAL) {
+        if (pos >= cap) break;
+        rd_drop(r, F::total(e));
+        if (lig == 0) dst[pos] = (uint8_t)F::literal(e);
+        last       = F::literal(e);
+        last_known = true;
+        pos++;
+        continue;
+      }
+      if (e) {                                       // end of block (0: no code)
+        rd_drop(r, F::total(e));
         ok = COMPACT_END;
       }
       break;
     }
-    uint32_t xb  = (e & F::F_L258) ? 0u : F::xbits(e);
+    uint32_t cl  = F::codelen(e);
+    uint32_t xb  = F::xbits(e);
     uint32_t len = F::len_base(e) + ((b >> cl) & ((1u << xb) - 1u));
-    rd_drop(r, cl + xb);
+    rd_drop(r, F::total(e));
 
     rd_fill(r);
     b = (uint32_t)r.bits;
     e = dist[b & ((1u << F::DIST_BITS) - 1u)];
-    if (e & F::F_SUB) e = dist[F::sub_at(e) + ((b >> F::DIST_BITS) & ((1u << (e & 15u)) - 1u))];
-    cl = e & 15u;
+    if (F::is_sub(e)) e = dist[F::sub_at(e) + ((b >> F::DIST_BITS) & ((1u << F::sub_bits(e)) - 1u))];
+    cl = F::codelen(e);
     xb = F::xbits(e);
     uint32_t d = F::dist_base(e) + ((b >> cl) & ((1u << xb) - 1u));
-    rd_drop(r, cl + xb);
+    rd_drop(r, F::total(e));
     if (!e || d > pos || len > cap - pos) break;   // d >= 1 for every real entry
 
     if (pend_off != NONE) dst[pend_off] = (uint8_t)pend_val;
@@ -1379,22 +1387,28 @@ __device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t rel) {
   return __builtin_amdgcn_alignbit(c.in[k + 64u], c.in[k], rel);
 }
 
-// Per-lane decoder state.  One step decodes ONE code: a literal/length code (ph = 0) or,
-// after a length code, the distance code (ph = 1).  The step is straight-line code (selects,
-// no divergent branches but the rare second-level table): all 64 lanes run it together
-// whatever kind of code each of them meets.  A lane goes on while p < lim: lim is the end of
-// its stretch, everything while it is inside a match, nothing once it has stopped.
+// Per-lane decoder state.  One step decodes ONE code: a literal/length code or, after a length
+// code, the distance code.  The step is straight-line code (selects, no divergent branches but
+// the rare second-level table): all 64 lanes run it together whatever kind of code each of them
+// meets.  Which table the next code is looked up in travels as the table's address and index
+// mask (msk = PL_DMASK: a distance code is due), chosen when the code before it is classified,
+// so a step begins with the look-up itself.  A lane goes on while p < lim: lim is the end of its
+// stretch, everything while it is inside a match, nothing once it has stopped.
+constexpr uint32_t PL_LMASK = (1u << CompactFmt::LIT_BITS) - 1u, PL_DMASK = (1u << CompactFmt::DIST_BITS) - 1u;
 struct ParLane {
-  uint32_t p, ph, o;             // bit position (relative to the lane's column), phase, bytes produced
-  uint32_t lim, limit, last;     // see above; the entry decoded last (0 = there was no such code)
-  uint32_t st;                   // 3 = stopped by the byte cap
+  uint32_t        p, o;          // bit position (relative to the lane's column), bytes produced
+  uint32_t        msk;           // index mask of the table the next code is looked up in
+  const uint16_t *tab;           // that table
+  uint32_t        lim, limit, last;   // see above; the entry decoded last (0 = there was no such code)
+  uint32_t        st;            // 3 = stopped by the byte cap
 };
 
 // p and limit are positions in the stream; the lane keeps them relative to its column
 __device__ __forceinline__ void pl_init(ParLane &b, const ParCtx &c, uint32_t p, uint32_t o, uint32_t limit,
                                         bool enable) {
   b.p     = p - c.colbit;
-  b.ph    = 0;
+  b.msk   = PL_LMASK;
+  b.tab   = c.lit;
   b.o     = o;
   b.st    = 0;
   b.last  = 1;
@@ -1402,48 +1416,46 @@ __device__ __forceinline__ void pl_init(ParLane &b, const ParCtx &c, uint32_t p,
   b.lim   = enable ? b.limit : 0u;
 }
 __device__ __forceinline__ uint32_t pl_pos(const ParLane &b, const ParCtx &c) { return b.p + c.colbit; }
+__device__ __forceinline__ bool pl_in_match(const ParLane &b) { return b.msk != PL_LMASK; }
 
 // Decodes the code at the lane's position.  MODE 0: positions only (the first scan looks for
 // where a chain ends); MODE 1: also counts the bytes produced; MODE 2: also returns `value`:
 // the literal byte, or distance - 1 after a distance code.  What kind of code it was shows in
-// the lane's state afterwards: ph = 1 after a length code, lim = 0 after anything that ends the
-// walk, lim = limit after a literal or a distance.  Whether a code runs past the end of the
-// stream is checked by the caller once per scan (the staged input is zero padded).
+// the lane's state afterwards: pl_in_match() after a length code, lim = 0 after anything that
+// ends the walk, lim = limit after a literal or a distance.  Whether a code runs past the end of
+// the stream is checked by the caller once per scan (the staged input is zero padded).
 template <int MODE>
 __device__ __forceinline__ void pl_step(ParLane &r, const ParCtx &c, uint32_t &value) {
   typedef CompactFmt F;
-  static_assert(F::F_LITERAL == 0x8000u && F::F_BASE == 0x4000u, "the entry classes are told apart by magnitude");
-  const uint32_t  b     = par_peek(c, r.p);
-  const bool      isd   = r.ph != 0;
-  const uint32_t  mbits = isd ? (uint32_t)F::DIST_BITS : (uint32_t)F::LIT_BITS;
-  const uint16_t *tab   = isd ? c.dist : c.lit;
-  uint32_t        e     = tab[b & ((1u << mbits) - 1u)];
+  const uint32_t b   = par_peek(c, r.p);
+  const bool     isd = r.msk != PL_LMASK;            // (MODE 2 only)
+  uint32_t       e   = r.tab[b & r.msk];
 #ifdef DEFL_PAR_PROFILE_STEPS                       // (atomics per step: distorts the cycle counts)
   if (threadIdx.x == (unsigned)__builtin_ctzll(__ballot(true))) {
     atomicAdd(&g_par_prof[30], 1ull);
-    if (__ballot((e & F::F_SUB) != 0)) atomicAdd(&g_par_prof[31], 1ull);
+    if (__ballot(e >= F::C_SUB)) atomicAdd(&g_par_prof[31], 1ull);
   }
 #endif
-  if (e & F::F_SUB)                                  // second-level table (skipped when no lane needs it)
-    e = tab[F::sub_at(e) + ((b >> mbits) & ((1u << (e & 15u)) - 1u))];
-  // Entry classes by magnitude: >= 0x8000 literal, >= 0x4000 base + extra bits (a length in the
-  // literal/length table, every entry of the distance table), below: end of block, 0 = no such
-  // code.  Each condition feeds selects directly; conditions are never combined.
-  const uint32_t cl      = e & 15u;
-  const uint32_t base    = (e >> 14) & 1u;                   // 1 for a base + extra bits entry only
-  const uint32_t x       = ((e >> 4) & 15u) * base;          // extra bits (a literal keeps its byte there)
-  const bool     goon    = e >= 0x4000u;
-  const bool     tomatch = base > r.ph;                      // a length code: the distance code follows
-  r.p += cl + x;
+  if (e >= F::C_SUB) {                               // second-level table (skipped when no lane needs it)
+    const uint32_t mbits = r.msk == PL_LMASK ? (uint32_t)F::LIT_BITS : (uint32_t)F::DIST_BITS;
+    e = r.tab[F::sub_at(e) + ((b >> mbits) & ((1u << F::sub_bits(e)) - 1u))];
+  }
+  // Entry classes by magnitude (see CompactFmt): each condition is one comparison that feeds
+  // selects directly; conditions are never combined.
+  const bool goon    = e >= F::C_DIST;               // a literal, a length or a distance
+  const bool tomatch = e >= F::C_LENGTH;             // a length code: the distance code follows
+  r.p += e & 31u;
   if (MODE >= 1) {
-    const uint32_t extra = (b >> cl) & ((1u << x) - 1u);
-    const uint32_t mant  = (((e >> 8) & 7u) << x) + extra;
+    const uint32_t cl    = (e >> 5) & 15u;
+    const uint32_t extra = __builtin_amdgcn_ubfe(b, cl, (e & 31u) - cl);   // (a literal: not used)
+    const uint32_t mant  = (((e >> 9) & 7u) << ((e & 31u) - cl)) + extra;
     const uint32_t len   = (e & F::F_L258) ? 258u : 3u + mant;
-    r.o += tomatch ? len : e >> 15;                          // a distance entry adds nothing
-    if (MODE == 2) value = isd ? mant : (e >> 4) & 0xffu;    // unused after a length code
+    r.o += tomatch ? len : (e >> 14) & 1u;                   // a distance entry adds nothing
+    if (MODE == 2) value = isd ? mant : (e >> 5) & 0xffu;    // unused after a length code
   }
   r.last = e;
-  r.ph   = tomatch ? 1u : 0u;
+  r.tab  = tomatch ? c.dist : c.lit;
+  r.msk  = tomatch ? PL_DMASK : PL_LMASK;
   r.lim  = tomatch ? ~0u : r.limit;
   r.lim  = goon ? r.lim : 0u;
 }
@@ -1483,15 +1495,15 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
       it++;
     }
     if (FULL && q < 3 && !all_done) {
-      if (__ballot(r.ph != 0)) {                     // lanes inside a match finish it first
-        if (r.ph) {
+      if (__ballot(pl_in_match(r))) {                // lanes inside a match finish it first
+        if (pl_in_match(r)) {
           uint32_t value;
           pl_step<1>(r, c, value);
         }
       }
       ck[q] = ((pl_pos(r, c) - round0) << 12) | r.o;
       nq    = q + 1;
-      if (!r.ph && r.o >= PAR_LANE_CAP && r.p < r.lim) {   // byte cap: the round ends with this lane
+      if (!pl_in_match(r) && r.o >= PAR_LANE_CAP && r.p < r.lim) {   // byte cap: the round ends with this lane
         r.st  = 3;
         r.lim = 0;
       }
@@ -1745,7 +1757,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
           if (rl.p < rl.lim) {
             uint32_t       value;
             const uint32_t at  = o0 + rl.o;
-            const bool     isd = rl.ph != 0;
+            const bool     isd = pl_in_match(rl);
             pl_step<2>(rl, cq, value);
             // one store serves both kinds of head: a literal at its own byte, a match (once its
             // distance is known) at the byte the length code stood for; a length code stores nothing
@@ -1753,7 +1765,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
             const uint32_t head  = (isd ? LK_EXT : LK_LIT) | value;
             const uint32_t dist  = isd ? value + 1u : 0u;
             if (rl.lim == rl.limit) P.link[where] = (uint16_t)head;
-            oh = rl.ph ? at : oh;
+            oh = pl_in_match(rl) ? at : oh;
             if (dist > pos + where) {                // distance reaches before the output start
               bad    = true;
               rl.lim = 0;

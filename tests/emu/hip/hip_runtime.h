@@ -120,6 +120,12 @@ static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetc
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 static inline uint32_t atomicAnd(uint32_t *p, uint32_t v) { return __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
 // v_alignbyte_b32: bytes [s, s + 4) of the 8-byte value hi:lo (s taken modulo 4)
+// v_bfe_u32: offset and width come from the low five bits of their operands; width 0 gives 0
+static inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t off, uint32_t width) {
+  off &= 31u;
+  width &= 31u;
+  return width ? (v >> off) & ((1u << width) - 1u) : 0u;
+}
 static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (s & 3u)));
 }
