@@ -25,6 +25,7 @@ EXPORTS = [
     "infl_many", "infl_gpu_malloc", "infl_gpu_free", "infl_gpu_upload", "infl_gpu_download",
     "infl_gpu_sync", "infl_gpu_set_lanes_per_stream", "infl_gpu_set_table_variant",
     "infl_batch_noalloc", "infl_batch_dev_checked", "infl_batch_checked", "infl_png_unfilter_dev", "infl_gather_dev",
+    "infl_gather_dev_checked", "infl_png_unfilter_dev_checked",
 ]
 
 
@@ -127,6 +128,8 @@ class Engine:
             "infl_batch_checked": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp]),
             "infl_png_unfilter_dev": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]),
             "infl_gather_dev": (i32, [vp, vp, vp, vp, sz, vp, vp]),
+            "infl_gather_dev_checked": (i32, [vp, C.c_uint64, vp, vp, vp, sz, vp, C.c_uint64, vp, vp]),
+            "infl_png_unfilter_dev_checked": (i32, [vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp, sz, vp, vp]),
             "infl_many": (i32, [vp, sz, vp]),
             "infl_gpu_malloc": (vp, [sz]),
             "infl_gpu_free": (None, [vp]),

@@ -63,9 +63,14 @@ typedef struct InflResume {
 
 /* Enqueues the one-stream incremental decode: src[0 .. srclen) is all the input seen so far,
    dst[0 .. cap) the output so far and the room behind it, *state (device memory) where the last
-   call stopped and where this one does.  0 or -1. */
-int infl_launch_resume(const void *src, uint32_t srclen, void *dst, uint32_t cap, int zlib,
-                       InflResume *state, void *stream);
+   call stopped and where this one does.  fresh (may be NULL): host memory the device can read,
+   holding input bytes fresh_at .. srclen, which the kernel moves into src first.  hout / hstate
+   (may be NULL): host memory the device can write; the call's new output bytes (at most hout_cap)
+   and a copy of the state go there.  The state's `reserved` word is the output position before
+   the call.  0 or -1. */
+int infl_launch_resume(void *src, uint32_t srclen, void *dst, uint32_t cap, int zlib,
+                       InflResume *state, const void *fresh, uint32_t fresh_at, void *hout,
+                       uint32_t hout_cap, InflResume *hstate, void *stream);
 
 /* Enqueues the batch kernel; all pointers are device pointers; `detail` (why a
    stream stopped) and `inpos` (input bytes consumed) may be NULL.  lanes =
@@ -97,12 +102,17 @@ typedef struct InflPngGeom {
   uint32_t rows, rowbytes, bpp, reserved;
 } InflPngGeom;
 #endif
+/* in_bytes / out_bytes: sizes of the two arenas where the caller knows them (else ~0): an image whose
+   ranges reach beyond them fails with status -1 and is not touched. */
 int infl_launch_png_unfilter(const void *in, const uint64_t *in_off, const uint32_t *in_len,
                              const int32_t *in_status, void *out, const uint64_t *out_off,
-                             const InflPngGeom *geom, uint64_t n, int32_t *status, void *stream);
+                             const InflPngGeom *geom, uint64_t n, int32_t *status, void *stream,
+                             uint64_t in_bytes, uint64_t out_bytes);
 
+/* blob_bytes / out_bytes as above; piece_status (may be NULL) gets 0 or -1 per piece. */
 int infl_launch_gather(const void *blob, const uint64_t *piece_off, const uint32_t *piece_len,
-                       const uint64_t *piece_dst, uint64_t n_pieces, void *out, void *stream);
+                       const uint64_t *piece_dst, uint64_t n_pieces, void *out, void *stream,
+                       uint64_t blob_bytes, uint64_t out_bytes, int32_t *piece_status);
 
 /* A pinned host buffer for gathering many streams' input before infl_rt_batch_host() (copies
    from pinned memory run at the full link rate).  One buffer per process: returns NULL when it is

@@ -68,6 +68,18 @@ static __device__ __align__(256) unsigned char scratch[kNaTotal];
 
 unsigned char *g_scratch_ptr[MAX_DEV] = {};            // device address of `scratch` per device (under g_mu[dev])
 
+// One stream of the library's own per device (default priority, not synchronising with the null
+// stream) for the calls that upload, decode, download and wait: infl_stream() steps and
+// infl_batch_noalloc().  Made by infl_gpu_init() or on first use; caller holds g_mu[dev].
+hipStream_t g_aux_stream[MAX_DEV] = {};
+hipStream_t aux_stream_on(int dev) {
+  if (!g_aux_stream[dev] && hipStreamCreateWithFlags(&g_aux_stream[dev], hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    g_aux_stream[dev] = nullptr;
+  }
+  return g_aux_stream[dev];
+}
+
 // Looks the array's address up on the current device (once per device); caller holds g_mu[dev].
 unsigned char *scratch_on(int dev) {
   if (!g_scratch_ptr[dev]) {
@@ -161,7 +173,7 @@ int infl_gpu_init(int device) {
   if (hipFree(nullptr) != hipSuccess) return -1;     // forces context creation
   if (device < MAX_DEV) {
     std::lock_guard<std::mutex> lock(g_mu[device]);
-    if (!scratch_on(device)) return -1;
+    if (!scratch_on(device) || !aux_stream_on(device)) return -1;
   }
   return 0;
 }
@@ -241,14 +253,34 @@ int infl_png_unfilter_dev(const void *dev_in, const uint64_t *dev_in_off, const 
   if (n == 0) return 0;
   if (!dev_in || !dev_in_off || !dev_out || !dev_out_off || !dev_geom || !dev_status) return -1;
   return infl_launch_png_unfilter(dev_in, dev_in_off, dev_in_len, dev_in_status, dev_out, dev_out_off, dev_geom, n,
-                                  dev_status, hip_stream);
+                                  dev_status, hip_stream, ~0ull, ~0ull);
+}
+
+int infl_png_unfilter_dev_checked(const void *dev_in, uint64_t in_bytes, const uint64_t *dev_in_off,
+                                  const uint32_t *dev_in_len, const int32_t *dev_in_status, void *dev_out,
+                                  uint64_t out_bytes, const uint64_t *dev_out_off, const InflPngGeom *dev_geom, size_t n,
+                                  int32_t *dev_status, void *hip_stream) {
+  if (n == 0) return 0;
+  if (!dev_in || !dev_in_off || !dev_out || !dev_out_off || !dev_geom || !dev_status) return -1;
+  return infl_launch_png_unfilter(dev_in, dev_in_off, dev_in_len, dev_in_status, dev_out, dev_out_off, dev_geom, n,
+                                  dev_status, hip_stream, in_bytes, out_bytes);
 }
 
 int infl_gather_dev(const void *dev_blob, const uint64_t *dev_piece_off, const uint32_t *dev_piece_len,
                     const uint64_t *dev_piece_dst, size_t n_pieces, void *dev_src, void *hip_stream) {
   if (n_pieces == 0) return 0;
   if (!dev_blob || !dev_piece_off || !dev_piece_len || !dev_piece_dst || !dev_src) return -1;
-  return infl_launch_gather(dev_blob, dev_piece_off, dev_piece_len, dev_piece_dst, n_pieces, dev_src, hip_stream);
+  return infl_launch_gather(dev_blob, dev_piece_off, dev_piece_len, dev_piece_dst, n_pieces, dev_src, hip_stream,
+                            ~0ull, ~0ull, nullptr);
+}
+
+int infl_gather_dev_checked(const void *dev_blob, uint64_t blob_bytes, const uint64_t *dev_piece_off,
+                            const uint32_t *dev_piece_len, const uint64_t *dev_piece_dst, size_t n_pieces, void *dev_src,
+                            uint64_t src_bytes, int32_t *dev_piece_status, void *hip_stream) {
+  if (n_pieces == 0) return 0;
+  if (!dev_blob || !dev_piece_off || !dev_piece_len || !dev_piece_dst || !dev_src) return -1;
+  return infl_launch_gather(dev_blob, dev_piece_off, dev_piece_len, dev_piece_dst, n_pieces, dev_src, hip_stream,
+                            blob_bytes, src_bytes, dev_piece_status);
 }
 
 static Buf  g_pin;                 // see infl_rt_pinned_acquire
@@ -459,12 +491,18 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
 }
 
 // ---- infl_stream(): one device context per stream object ------------------------------------
-// The input seen so far and the output produced so far stay on the device between calls, so a
-// call uploads only the new input bytes and downloads only the new output bytes.
+// The input seen so far and the output produced so far stay on the device between calls.  A call
+// is one launch and one wait: the new input bytes lie in a pinned buffer the kernel reads itself,
+// and the kernel stores the new output bytes and its state to pinned memory too (a feed or an
+// output larger than the staging takes the copy engine for the rest).  Calls on one GPU take
+// turns (the per-device lock): they share the library's stream there.
+constexpr size_t kStageIn = 64u << 10, kStageOut = 64u << 10;
 struct StreamCtx {
   void       *d_src = nullptr, *d_dst = nullptr;
   size_t      src_cap = 0, src_up = 0, dst_cap = 0;
   InflResume *d_state = nullptr;
+  uint8_t    *pin = nullptr;              // [InflResume | pad to 64][kStageIn input][kStageOut output]
+  int         dev = 0;
 };
 
 void infl_rt_stream_free(void *ctx) {
@@ -473,6 +511,7 @@ void infl_rt_stream_free(void *ctx) {
   if (c->d_src) (void)hipFree(c->d_src);
   if (c->d_dst) (void)hipFree(c->d_dst);
   if (c->d_state) (void)hipFree(c->d_state);
+  if (c->pin) (void)hipHostFree(c->pin);
   delete c;
 }
 
@@ -480,18 +519,28 @@ int infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst,
                         uint32_t dstpos, int zlib, InflResume *out) {
   if (!ctxp || !out || acc_len > 0xffffffffu) return -1;
   if (!device_ready()) return -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
+  std::lock_guard<std::mutex> lock(g_mu[dev]);
+  hipStream_t st = aux_stream_on(dev);
+  if (!st) return -1;
   StreamCtx *c = (StreamCtx *)*ctxp;
+  if (c && c->dev != dev) return -1;                  // a stream stays on the GPU it began on
   if (!c) {
     c = new (std::nothrow) StreamCtx();
     if (!c) return -12;
+    c->dev = dev;
     if (hipMalloc((void **)&c->d_state, sizeof(InflResume)) != hipSuccess ||
-        hipMemset(c->d_state, 0, sizeof(InflResume)) != hipSuccess) {
+        hipMemsetAsync(c->d_state, 0, sizeof(InflResume), st) != hipSuccess ||
+        hipHostMalloc((void **)&c->pin, 64 + kStageIn + kStageOut, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
       infl_rt_stream_free(c);
       return -12;
     }
     *ctxp = c;
   }
+  InflResume *hstate = (InflResume *)c->pin;
+  uint8_t    *hin = c->pin + 64, *hout = hin + kStageIn;
   if (acc_len + 16 > c->src_cap) {                    // grow the input arena: everything goes up again
     const size_t want = std::max(acc_len + 16 + acc_len / 2, (size_t)4096);
     void *n = nullptr;
@@ -499,7 +548,10 @@ int infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst,
       (void)hipGetLastError();
       return -12;
     }
-    if (c->d_src) (void)hipFree(c->d_src);
+    if (c->d_src) {
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(c->d_src);
+    }
     c->d_src   = n;
     c->src_cap = want;
     c->src_up  = 0;
@@ -512,28 +564,58 @@ int infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst,
       return -12;
     }
     bool ok = true;
-    if (c->d_dst && dstpos) ok = hipMemcpy(n, c->d_dst, std::min((size_t)dstpos, c->dst_cap), hipMemcpyDeviceToDevice) == hipSuccess;
+    if (c->d_dst && dstpos)
+      ok = hipMemcpyAsync(n, c->d_dst, std::min((size_t)dstpos, c->dst_cap), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+           hipStreamSynchronize(st) == hipSuccess;
     if (c->d_dst) (void)hipFree(c->d_dst);
     c->d_dst   = n;
     c->dst_cap = want;
     if (!ok) return -1;
   }
-  bool ok = true;
-  if (acc_len > c->src_up) {
-    ok &= hipMemcpy((uint8_t *)c->d_src + c->src_up, (const uint8_t *)acc + c->src_up, acc_len - c->src_up,
-                    hipMemcpyHostToDevice) == hipSuccess;
-    c->src_up = acc_len;
+  bool           ok = true;
+  const uint8_t *fresh = nullptr;
+  const size_t   fresh_at = c->src_up, fresh_len = acc_len - c->src_up;
+  if (fresh_len > kStageIn) {                         // a large feed: the copy engine
+    ok &= hipMemcpyAsync((uint8_t *)c->d_src + fresh_at, (const uint8_t *)acc + fresh_at, fresh_len,
+                         hipMemcpyHostToDevice, st) == hipSuccess;
+  } else if (fresh_len) {
+    memcpy(hin, (const uint8_t *)acc + fresh_at, fresh_len);
+    fresh = hin;
   }
-  ok = ok && infl_launch_resume(c->d_src, (uint32_t)acc_len, c->d_dst, dstlen, zlib ? 1 : 0, c->d_state, nullptr) == 0;
-  ok = ok && hipMemcpy(out, c->d_state, sizeof(InflResume), hipMemcpyDeviceToHost) == hipSuccess;
-  if (ok && out->pos > dstpos && out->pos <= dstlen)
-    ok = hipMemcpy((uint8_t *)dst + dstpos, (const uint8_t *)c->d_dst + dstpos, out->pos - dstpos,
-                   hipMemcpyDeviceToHost) == hipSuccess;
+  c->src_up = acc_len;
+  ok = ok && infl_launch_resume(c->d_src, (uint32_t)acc_len, c->d_dst, dstlen, zlib ? 1 : 0, c->d_state, fresh,
+                                (uint32_t)fresh_at, hout, (uint32_t)kStageOut, hstate, st) == 0;
+  ok = ok && hipStreamSynchronize(st) == hipSuccess;
+  if (ok) {
+    *out = *hstate;
+    ok = out->reserved == dstpos && out->pos >= dstpos && out->pos <= dstlen;   // (the device began where the host stands)
+  }
+  if (ok && out->pos > dstpos) {
+    const size_t got = out->pos - dstpos, staged = std::min(got, kStageOut);
+    memcpy((uint8_t *)dst + dstpos, hout, staged);
+    if (got > staged)
+      ok = hipMemcpyAsync((uint8_t *)dst + dstpos + staged, (const uint8_t *)c->d_dst + dstpos + staged, got - staged,
+                          hipMemcpyDeviceToHost, st) == hipSuccess &&
+           hipStreamSynchronize(st) == hipSuccess;
+  }
   if (!ok) {
+    (void)hipStreamSynchronize(st);
     (void)hipGetLastError();
     return -1;
   }
   return 0;
+}
+
+// Clears what lies behind every stream's output in the destination arena of infl_batch_noalloc (one
+// wavefront per stream), so that the one copy that hands the arena back carries nothing of earlier calls.
+__global__ __launch_bounds__(64) void infl_clear_tail_kernel(unsigned char *__restrict__ dst,
+                                                            const uint64_t *__restrict__ dst_off,
+                                                            const uint32_t *__restrict__ outlen, uint64_t n) {
+  for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint64_t d0 = dst_off[i], cap = dst_off[i + 1] - d0;
+    const uint64_t from = outlen[i] < cap ? outlen[i] : cap;
+    for (uint64_t k = from + threadIdx.x; k < cap; k += 64) dst[d0 + k] = 0;
+  }
 }
 
 int infl_batch_noalloc(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
@@ -549,6 +631,8 @@ int infl_batch_noalloc(const void *src, const uint64_t *src_off, void *dst, cons
     return -105;                                       // UNZ_EFULL
   }
   if ((src_bytes && !src) || (dst_bytes && !dst)) return -1;
+  for (size_t i = 0; i < n; i++)                       // the regions of the one array lie side by side: a stream's
+    if (src_off[i] > src_off[i + 1] || dst_off[i] > dst_off[i + 1]) return -1;   // range must not reach into another
   if (!device_ready()) return -1;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
@@ -556,13 +640,14 @@ int infl_batch_noalloc(const void *src, const uint64_t *src_off, void *dst, cons
   // Calls on one GPU share that GPU's array: the lock keeps host threads apart (a caller that
   // bypasses it, e.g. from two processes' worth of streams, would race).  Nothing in the array
   // has to start at zero: every stream's status, length and bytes are written by the kernels
-  // before they are read back, whatever the last call left behind.
+  // before they are read back, and what lies behind a stream's bytes is cleared before the
+  // arena goes back, whatever the last call left behind.
   std::lock_guard<std::mutex> lock(g_mu[dev]);
   unsigned char *base = scratch_on(dev);
   if (!base) return -1;
   const size_t   off_bytes = (n + 1) * sizeof(uint64_t);
-  hipStream_t    st = nullptr;
-  bool ok = true;
+  hipStream_t    st = g_aux_stream[dev];               // made by infl_gpu_init() (nothing is created here); without
+  bool ok = true;                                      // that call the null stream serves
   if (src_bytes) ok &= hipMemcpyAsync(base + kNaSrcAt, src, src_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
   ok &= hipMemcpyAsync(base + kNaSoffAt, src_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
   ok &= hipMemcpyAsync(base + kNaDoffAt, dst_off, off_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
@@ -571,10 +656,12 @@ int infl_batch_noalloc(const void *src, const uint64_t *src_off, void *dst, cons
                                (int32_t *)(base + kNaStatusAt), (uint32_t *)(base + kNaOutlenAt), nullptr, nullptr,
                                g_lanes.load(), g_variant.load(), nullptr, st, nullptr) == 0;
   if (ok) {
+    hipLaunchKernelGGL(infl_clear_tail_kernel, dim3((unsigned)n), dim3(64), 0, st, base + kNaDstAt,
+                       (const uint64_t *)(base + kNaDoffAt), (const uint32_t *)(base + kNaOutlenAt), (uint64_t)n);
+    ok &= hipGetLastError() == hipSuccess;
     ok &= hipMemcpyAsync(status, base + kNaStatusAt, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
     ok &= hipMemcpyAsync(outlen, base + kNaOutlenAt, n * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-    // the whole destination arena in one copy: behind a stream's outlen[i] bytes its share holds
-    // whatever the decoder left there (the reference leaves that part unspecified too)
+    // the whole destination arena in one copy (zero behind every stream's bytes)
     if (dst_bytes) ok &= hipMemcpyAsync(dst, base + kNaDstAt, dst_bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
   }
   const bool drained = hipStreamSynchronize(st) == hipSuccess;

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <sys/mman.h>
 
 #include "../../include/defl/infl.h"
 #include "../../include/defl/infl_batch.h"
@@ -37,6 +38,72 @@
 
 #define PAGE_SIZE        32768u   /* UNZ_CHUNK_PAGE_SIZE,        src/common.h:45 */
 #define APPEND_THRESHOLD 8192u    /* UNZ_CHUNK_APPEND_THRESHOLD, src/common.h:46 */
+
+/* Process-wide pool of the 32 KiB pages small pieces are copied into (the reference pools them per
+   stream, src/infl/mem.c:35-105; its pools die with the stream, so a program that makes one stream
+   per image pays for fresh pages every time).  Pages are carved from slabs aligned to 2 MiB for
+   which huge pages are asked (the first touch of a page otherwise costs a fault per 4 KiB, which
+   is what infl_include cost on fresh streams: 3.4 us per call against 0.7 us on reused ones), go
+   back to a free list with infl_destroy() and are handed out again, already touched, to the next
+   stream.  Beyond POOL_KEEP_PAGES free pages the memory of a returned page is given back to the
+   system (the address stays in the list). */
+#define HUGE_BYTES      (2u << 20)
+#define SLAB_BYTES      (8u << 20)
+#define POOL_KEEP_PAGES 8192u      /* 256 MiB of touched pages kept for reuse */
+
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static uint8_t       **g_pool_free;
+static size_t          g_pool_nfree, g_pool_cap;
+static uint8_t        *g_slab;
+static size_t          g_slab_left;
+
+static uint8_t *
+page_acquire(void) {
+  uint8_t *pg = NULL;
+  pthread_mutex_lock(&g_pool_mu);
+  if (g_pool_nfree) {
+    pg = g_pool_free[--g_pool_nfree];
+  } else {
+    if (g_slab_left < PAGE_SIZE) {
+      void *m = mmap(NULL, SLAB_BYTES + HUGE_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m != MAP_FAILED) {
+        g_slab      = (uint8_t *)(((uintptr_t)m + HUGE_BYTES - 1u) & ~(uintptr_t)(HUGE_BYTES - 1u));
+        g_slab_left = SLAB_BYTES;
+#ifdef MADV_HUGEPAGE
+        (void)madvise(g_slab, SLAB_BYTES, MADV_HUGEPAGE);   /* (where the system declines, ordinary pages serve) */
+#endif
+      }
+    }
+    if (g_slab_left >= PAGE_SIZE) {
+      pg           = g_slab;
+      g_slab      += PAGE_SIZE;
+      g_slab_left -= PAGE_SIZE;
+    }
+  }
+  pthread_mutex_unlock(&g_pool_mu);
+  return pg;
+}
+
+static void
+page_release(uint8_t *pg) {
+  pthread_mutex_lock(&g_pool_mu);
+  if (g_pool_nfree == g_pool_cap) {
+    size_t    cap = g_pool_cap ? g_pool_cap * 2 : 256;
+    uint8_t **np  = (uint8_t **)realloc(g_pool_free, cap * sizeof(*np));
+    if (np) {
+      g_pool_free = np;
+      g_pool_cap  = cap;
+    }
+  }
+  if (g_pool_nfree < g_pool_cap) {
+    if (g_pool_nfree >= POOL_KEEP_PAGES)
+      (void)madvise(pg, PAGE_SIZE, MADV_DONTNEED);
+    g_pool_free[g_pool_nfree++] = pg;
+  } else {
+    (void)madvise(pg, PAGE_SIZE, MADV_DONTNEED);      /* no room to remember it: the address is lost, the memory is not held */
+  }
+  pthread_mutex_unlock(&g_pool_mu);
+}
 
 typedef struct piece_t {
   const uint8_t *p;
@@ -65,8 +132,10 @@ struct unz__stream_t {
   size_t    gather_cap;
 
   int       stream_done;          /* infl_stream() reached the final block */
-  uint8_t  *acc;                  /* infl_stream(): every input byte fed so far, contiguous */
+  int       stream_started;       /* infl_stream() has begun to decode (the reference's state != NONE) */
+  uint8_t  *acc;                  /* infl_stream(): the piece list so far as one contiguous range (what the device sees) */
   size_t    acc_len, acc_cap;
+  size_t    mir_piece, mir_off;   /* first piece, and bytes of it, not yet copied to acc */
   void     *sctx;                 /* its device context (input, output and decode position stay on the device) */
 };
 
@@ -100,6 +169,9 @@ infl_reset_pool(infl_stream_t * __restrict st) {
   st->page_fill  = 0;
   st->appending  = 0;
   st->acc_len    = 0;
+  st->mir_piece  = 0;
+  st->mir_off    = 0;
+  st->stream_started = 0;
   if (st->sctx) {                                 /* the incremental decode starts over with the input */
     infl_rt_stream_free(st->sctx);
     st->sctx = NULL;
@@ -143,7 +215,7 @@ infl_destroy(infl_stream_t * __restrict st) {
   if (!st)
     return;
   for (size_t i = 0; i < st->npages; i++)
-    free(st->pages[i]);
+    page_release(st->pages[i]);
   free(st->pages);
   free(st->pieces);
   free(st->gather);
@@ -178,7 +250,8 @@ next_page(infl_stream_t *st, int32_t *index) {
       st->pages    = np;
       st->cappages = cap;
     }
-    if (posix_memalign((void **)&pg, 64, PAGE_SIZE) != 0)
+    pg = page_acquire();
+    if (!pg)
       return NULL;
     st->pages[st->npages++] = pg;
   }
@@ -315,10 +388,14 @@ acc_append(infl_stream_t *st, const void *p, size_t len) {
 }
 
 /* Incremental decode (reference src/infl/stream.c:468-794): every call adds its bytes to the input
-   and decodes on from where the last call stopped (a block header or a symbol boundary; the GPU
-   keeps input, output and position, see infl_resume_kernel).  UNZ_UNFINISHED while the stream wants
-   more input, UNZ_EFULL when the output buffer is full (go on after infl_resize_output), UNZ_OK once
-   the final block is complete. */
+   with infl_include(), like the reference (stream.c:481-482), so infl_include() and infl_stream()
+   may be mixed on one object and a later infl() sees the same input.  The decode goes on from
+   where the last call stopped (a block header or a symbol boundary; the GPU keeps input, output
+   and position, see infl_resume_kernel); `acc` is the piece list as one contiguous range, extended
+   by whatever the list has gained since the last call.  UNZ_UNFINISHED while the stream wants more
+   input, UNZ_EFULL when the output buffer is full (go on after infl_resize_output), UNZ_OK once
+   the final block is complete, UNZ_NOOP for a call without data before any decode has begun
+   (stream.c:505-507). */
 UNZ_EXPORT int
 infl_stream(infl_stream_t * __restrict st, const void * __restrict src, uint32_t srclen) {
   InflResume rs;
@@ -326,19 +403,27 @@ infl_stream(infl_stream_t * __restrict st, const void * __restrict src, uint32_t
 
   if (!st)
     return UNZ_ERR;
-  if (st->acc_len == 0 && st->npieces) {          /* input given with infl_include() before: it comes first */
-    for (size_t i = 0; i < st->npieces; i++)
-      if (acc_append(st, st->pieces[i].p, st->pieces[i].len) != 0)
-        return UNZ_ENOMEM;
-  }
-  if (src && srclen > 0) {
-    if (acc_append(st, src, srclen) != 0)
-      return UNZ_ENOMEM;
-  } else if (st->acc_len == 0) {
+  if (src && srclen > 0)
+    infl_include(st, src, srclen);
+  else if (st->npieces == 0)
     return UNZ_OK;                                /* "empty data", stream.c:489-493 */
-  }
   if (st->stream_done)
     return UNZ_OK;
+  if (!src && srclen == 0 && !st->stream_started)
+    return UNZ_NOOP;
+  while (st->mir_piece < st->npieces) {           /* what the piece list has gained (its last piece may have grown) */
+    const piece_t *pc = &st->pieces[st->mir_piece];
+    if (pc->len > st->mir_off) {
+      if (acc_append(st, pc->p + st->mir_off, pc->len - st->mir_off) != 0)
+        return UNZ_ENOMEM;
+      st->mir_off = pc->len;
+    }
+    if (st->mir_piece + 1 == st->npieces)
+      break;
+    st->mir_piece++;
+    st->mir_off = 0;
+  }
+  st->stream_started = 1;
   if (st->acc_len > UINT32_MAX)
     return UNZ_ERR;
 

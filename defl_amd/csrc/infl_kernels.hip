@@ -2396,16 +2396,27 @@ __global__ __launch_bounds__(256) void infl_mark_kernel(int32_t *__restrict__ st
 // A stop is always at a block header or at a symbol boundary: a symbol that lacks input bits
 // or output space is left for the next call as a whole.
 // ---------------------------------------------------------------------------
+//
+// A call's traffic with the host rides on the launch itself when the host gives pinned buffers:
+// the new input bytes are fetched from `fresh` (host memory the device can read) into the input
+// arena at src[fresh_at ..) before the decode, the new output bytes (at most hout_cap of them) and
+// the state are stored to `hout` / `hstate` after it, so a call is one launch and one wait.
 template <int T>
-__global__ __launch_bounds__(64, 1) void infl_resume_kernel(const uint8_t *__restrict__ src, uint32_t srclen,
+__global__ __launch_bounds__(64, 1) void infl_resume_kernel(uint8_t *src, uint32_t srclen,
                                                              uint8_t *__restrict__ dst, uint32_t cap, int zlib,
-                                                             InflResume *__restrict__ state) {
+                                                             InflResume *__restrict__ state,
+                                                             const uint8_t *__restrict__ fresh, uint32_t fresh_at,
+                                                             uint8_t *__restrict__ hout, uint32_t hout_cap,
+                                                             InflResume *__restrict__ hstate) {
   typedef RefFmt F;
   static_assert(T == 64, "one wavefront decodes the stream");
   __shared__ StreamLds<F> L;
   const int lig = threadIdx.x;
   uint64_t  bit = state->bit, block_bit = state->block_bit;
   uint32_t  pos = state->pos, flags = state->flags;
+  const uint32_t pos_before = pos;
+  if (fresh && fresh_at < srclen)
+    for (uint32_t k = (uint32_t)lig; k < srclen - fresh_at; k += T) src[fresh_at + k] = fresh[k];
   group_sync();                                      // every lane has read the state before lane 0 writes it
   int       rc = INFL_D_OK;
   uint64_t  fuel = (uint64_t)srclen * 8u + 64u;
@@ -2474,12 +2485,20 @@ __global__ __launch_bounds__(64, 1) void infl_resume_kernel(const uint8_t *__res
   }
   if (rc != INFL_D_OK && !(flags & INFL_RS_INBLOCK)) bit = block_bit;
   group_sync();
+  if (hout) {
+    const uint32_t fresh_out = pos - pos_before < hout_cap ? pos - pos_before : hout_cap;
+    for (uint32_t k = (uint32_t)lig; k < fresh_out; k += T) hout[k] = dst[pos_before + k];
+  }
   if (lig == 0) {
-    state->bit       = bit;
-    state->block_bit = block_bit;
-    state->pos       = pos;
-    state->flags     = flags;
-    state->detail    = rc;
+    InflResume ns;
+    ns.bit       = bit;
+    ns.block_bit = block_bit;
+    ns.pos       = pos;
+    ns.flags     = flags;
+    ns.detail    = rc;
+    ns.reserved  = pos_before;                       // where this call's output begins
+    *state = ns;
+    if (hstate) *hstate = ns;
   }
 }
 
@@ -2985,7 +3004,7 @@ __device__ __forceinline__ bool png_unfilter_image(uint8_t *tile, const uint8_t 
 __device__ __forceinline__ void png_unfilter_one(uint8_t *tile, uint64_t i, uint32_t lane, const uint8_t *in,
                                                  const uint64_t *in_off, const uint32_t *in_len, const int32_t *in_status,
                                                  uint8_t *out, const uint64_t *out_off, const InflPngGeom *geom,
-                                                 int32_t *status) {
+                                                 int32_t *status, uint64_t in_bytes, uint64_t out_bytes) {
   const InflPngGeom g = geom[i];
   const uint64_t i0 = in_off[i], i1 = in_off[i + 1], o0 = out_off[i], o1 = out_off[i + 1];
   uint64_t have = i1 >= i0 ? i1 - i0 : 0;
@@ -2993,7 +3012,8 @@ __device__ __forceinline__ void png_unfilter_one(uint8_t *tile, uint64_t i, uint
   const uint32_t rows = g.rows, rb = g.rowbytes;
   const uint64_t need_in = (uint64_t)rows * ((uint64_t)rb + 1u), need_out = (uint64_t)rows * rb;
   const bool fits = g.bpp >= 1 && g.bpp <= 8 && need_in < 0xfffffc00ull && need_in <= have && o1 >= o0 &&
-                    need_out <= o1 - o0 && !(in_status && in_status[i] != 0);
+                    need_out <= o1 - o0 && !(in_status && in_status[i] != 0) &&
+                    i1 <= in_bytes && o1 <= out_bytes;   // (the arenas' sizes where the caller gives them, else ~0)
   if (!fits) {
     if (lane == 0) status[i] = -1;
     return;
@@ -3025,10 +3045,11 @@ __device__ __forceinline__ void png_unfilter_one(uint8_t *tile, uint64_t i, uint
 __global__ __launch_bounds__(64) void infl_png_unfilter_kernel(const uint8_t *in, const uint64_t *in_off,
                                                                 const uint32_t *in_len, const int32_t *in_status,
                                                                 uint8_t *out, const uint64_t *out_off,
-                                                                const InflPngGeom *geom, uint64_t n, int32_t *status) {
+                                                                const InflPngGeom *geom, uint64_t n, int32_t *status,
+                                                                uint64_t in_bytes, uint64_t out_bytes) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[65 * PNG_PITCH];
   for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
-    png_unfilter_one(tile, i, threadIdx.x, in, in_off, in_len, in_status, out, out_off, geom, status);
+    png_unfilter_one(tile, i, threadIdx.x, in, in_off, in_len, in_status, out, out_off, geom, status, in_bytes, out_bytes);
     group_sync();
   }
 }
@@ -3039,20 +3060,26 @@ __global__ __launch_bounds__(64) void infl_png_unfilter_kernel(const uint8_t *in
 // logical input).  Piece p is blob[piece_off[p] .. + piece_len[p]) and goes to out[piece_dst[p] ..): the
 // caller lays the pieces of a stream one behind the other and the streams into one arena.  One wavefront
 // per piece; a lane moves 16 bytes per access at whatever alignment source and target have (neighbouring
-// lanes, neighbouring bytes), the last bytes of a piece go one at a time.  Bounds are the caller's: the
-// launcher has no way to know how large the blob and the arena are.
+// lanes, neighbouring bytes), the last bytes of a piece go one at a time.  blob_bytes / out_bytes are the
+// sizes of the blob and of the arena where the caller gives them (~0 = not known): a piece that does not lie
+// inside both is not touched and gets piece_status -1 (piece_status may be null).
 // ---------------------------------------------------------------------------------------------
 struct __attribute__((packed)) Bytes16 { uint32_t w[4]; };          // 16 bytes at any address
 __global__ __launch_bounds__(64) void infl_gather_kernel(const uint8_t *__restrict__ blob,
                                                          const uint64_t *__restrict__ piece_off,
                                                          const uint32_t *__restrict__ piece_len,
                                                          const uint64_t *__restrict__ piece_dst, uint64_t n_pieces,
-                                                         uint8_t *__restrict__ out) {
+                                                         uint8_t *__restrict__ out, uint64_t blob_bytes,
+                                                         uint64_t out_bytes, int32_t *__restrict__ piece_status) {
   const uint32_t lane = threadIdx.x;
   for (uint64_t p = blockIdx.x; p < n_pieces; p += gridDim.x) {
-    const uint8_t *s   = blob + piece_off[p];
-    uint8_t       *d   = out + piece_dst[p];
+    const uint64_t so = piece_off[p], to = piece_dst[p];
     const uint32_t len = piece_len[p], body = len & ~15u;
+    const bool     inside = so <= blob_bytes && len <= blob_bytes - so && to <= out_bytes && len <= out_bytes - to;
+    if (piece_status && lane == 0) piece_status[p] = inside ? 0 : -1;
+    if (!inside) continue;
+    const uint8_t *s   = blob + so;
+    uint8_t       *d   = out + to;
     for (uint32_t k = 16u * lane; k < body; k += 1024u) *(Bytes16 *)(d + k) = *(const Bytes16 *)(s + k);
     if (lane < len - body) d[body + lane] = s[body + lane];
   }
@@ -3182,16 +3209,20 @@ extern "C" int infl_launch_checked(const void *src, const uint64_t *src_off, voi
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int infl_launch_resume(const void *src, uint32_t srclen, void *dst, uint32_t cap, int zlib,
-                                  InflResume *state, void *stream) {
-  hipLaunchKernelGGL((defl::infl_resume_kernel<64>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)src,
-                     srclen, (uint8_t *)dst, cap, zlib, state);
+extern "C" int infl_launch_resume(void *src, uint32_t srclen, void *dst, uint32_t cap, int zlib,
+                                  InflResume *state, const void *fresh, uint32_t fresh_at, void *hout,
+                                  uint32_t hout_cap, InflResume *hstate, void *stream) {
+  DEFL_LAUNCH_GROUP(64);
+  hipLaunchKernelGGL((defl::infl_resume_kernel<64>), dim3(1), dim3(64), 0, (hipStream_t)stream, (uint8_t *)src,
+                     srclen, (uint8_t *)dst, cap, zlib, state, (const uint8_t *)fresh, fresh_at, (uint8_t *)hout,
+                     hout_cap, hstate);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 extern "C" int infl_launch_png_unfilter(const void *in, const uint64_t *in_off, const uint32_t *in_len,
                                         const int32_t *in_status, void *out, const uint64_t *out_off,
-                                        const InflPngGeom *geom, uint64_t n, int32_t *status, void *stream) {
+                                        const InflPngGeom *geom, uint64_t n, int32_t *status, void *stream,
+                                        uint64_t in_bytes, uint64_t out_bytes) {
   if (n == 0) return 0;
   // as many workgroups as fit on the device at once (9 tiles in a compute unit's 160 KiB of LDS)
   static std::atomic<unsigned> resident[64];
@@ -3206,18 +3237,20 @@ extern "C" int infl_launch_png_unfilter(const void *in, const uint64_t *in_off, 
   }
   const unsigned grid = n < slots ? (unsigned)n : slots;
   hipLaunchKernelGGL(defl::infl_png_unfilter_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream,
-                     (const uint8_t *)in, in_off, in_len, in_status, (uint8_t *)out, out_off, geom, n, status);
+                     (const uint8_t *)in, in_off, in_len, in_status, (uint8_t *)out, out_off, geom, n, status, in_bytes,
+                     out_bytes);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 extern "C" int infl_launch_gather(const void *blob, const uint64_t *piece_off, const uint32_t *piece_len,
-                                  const uint64_t *piece_dst, uint64_t n_pieces, void *out, void *stream) {
+                                  const uint64_t *piece_dst, uint64_t n_pieces, void *out, void *stream,
+                                  uint64_t blob_bytes, uint64_t out_bytes, int32_t *piece_status) {
   if (n_pieces == 0) return 0;
   // pieces are a few bytes to a few KiB each: a grid of at most 64 Ki workgroups that take the pieces in turn
   const unsigned grid = n_pieces < 65536u ? (unsigned)n_pieces : 65536u;
   DEFL_LAUNCH_GROUP(64);
   hipLaunchKernelGGL(defl::infl_gather_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)blob,
-                     piece_off, piece_len, piece_dst, n_pieces, (uint8_t *)out);
+                     piece_off, piece_len, piece_dst, n_pieces, (uint8_t *)out, blob_bytes, out_bytes, piece_status);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

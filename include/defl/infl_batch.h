@@ -144,8 +144,9 @@ infl_png_unfilter_dev(const void *dev_in, const uint64_t *dev_in_off,
  * headers, lays the pieces of a stream one behind the other and the streams one behind the other, and
  * passes dev_src with the matching dev_src_off to infl_batch_dev().  Pieces of any length (0 included)
  * at any alignment; dev_src must not overlap the pieces it is gathered from.  No bounds are known to
- * the call: offsets and lengths must lie inside the caller's buffers.  Enqueues on hip_stream and
- * returns; 0, or -1 for a NULL argument or a launch that failed.
+ * this call: offsets and lengths must lie inside the caller's buffers (a descriptor that does not is
+ * a memory fault on the device; callers that take descriptors from files use the _checked form).
+ * Enqueues on hip_stream and returns; 0, or -1 for a NULL argument or a launch that failed.
  */
 UNZ_EXPORT int
 infl_gather_dev(const void *dev_blob, const uint64_t *dev_piece_off,
@@ -153,16 +154,40 @@ infl_gather_dev(const void *dev_blob, const uint64_t *dev_piece_off,
                 size_t n_pieces, void *dev_src, void *hip_stream);
 
 /*
+ * The two descriptor-driven calls with the sizes of their buffers, for descriptors that come from
+ * untrusted input (chunk headers of a file): blob_bytes / src_bytes are the sizes of dev_blob and
+ * dev_src, in_bytes / out_bytes those of dev_in and dev_out.  A piece that does not lie inside
+ * both of its buffers is not copied and gets dev_piece_status[p] = -1 (0 otherwise; the array may
+ * be NULL); an image whose input or output range reaches beyond its arena gets dev_status[i] = -1
+ * and is not touched.  No counterpart in the reference (mem.c:114-216 trusts its caller too).
+ */
+UNZ_EXPORT int
+infl_gather_dev_checked(const void *dev_blob, uint64_t blob_bytes,
+                        const uint64_t *dev_piece_off, const uint32_t *dev_piece_len,
+                        const uint64_t *dev_piece_dst, size_t n_pieces,
+                        void *dev_src, uint64_t src_bytes,
+                        int32_t *dev_piece_status, void *hip_stream);
+UNZ_EXPORT int
+infl_png_unfilter_dev_checked(const void *dev_in, uint64_t in_bytes, const uint64_t *dev_in_off,
+                              const uint32_t *dev_in_len, const int32_t *dev_in_status,
+                              void *dev_out, uint64_t out_bytes, const uint64_t *dev_out_off,
+                              const InflPngGeom *dev_geom, size_t n,
+                              int32_t *dev_status, void *hip_stream);
+
+/*
  * infl_batch() for callers that cannot allocate: tight serving loops, harnesses that forbid
- * hipMalloc, code that runs while a HIP graph is being captured elsewhere in the process.  It has
- * no counterpart in the reference.  Same arguments and results as infl_batch(), but the device
- * staging (source and destination arenas, offset tables, result arrays) is a fixed array inside
- * the library's code object, one copy per GPU, held until the process ends; the call allocates and
- * frees nothing.  Limits: n <= INFL_NOALLOC_MAX_STREAMS, src_off[n] <= INFL_NOALLOC_MAX_SRC,
- * dst_off[n] <= INFL_NOALLOC_MAX_DST; beyond them the call returns UNZ_EFULL and decodes nothing.
- * dst[dst_off[i] + outlen[i] .. dst_off[i + 1]) is unspecified afterwards (infl_batch() leaves it
- * untouched).  Calls on the same GPU share one array: the library serialises host threads of one
- * process on it; callers in different processes each have their own copy.
+ * hipMalloc.  It has no counterpart in the reference.  Same arguments and results as infl_batch(),
+ * but the device staging (source and destination arenas, offset tables, result arrays) is a fixed
+ * array inside the library's code object, one copy per GPU, held until the process ends; the call
+ * allocates and frees nothing (it runs on the stream infl_gpu_init() made for the device, on the
+ * null stream if that call was never made).  Limits: n <= INFL_NOALLOC_MAX_STREAMS, src_off[n]
+ * <= INFL_NOALLOC_MAX_SRC, dst_off[n] <= INFL_NOALLOC_MAX_DST; beyond them the call returns
+ * UNZ_EFULL and decodes nothing; offsets that decrease are refused with UNZ_ERR.
+ * dst[dst_off[i] + outlen[i] .. dst_off[i + 1]) is zero afterwards (infl_batch() leaves it
+ * untouched): the array keeps earlier calls' bytes, and none of them reaches a later caller.
+ * Calls on the same GPU share one array: the library serialises host threads of one process on it
+ * (calls that bypass that, e.g. from a signal handler, race); callers in different processes each
+ * have their own copy.
  */
 #define INFL_NOALLOC_MAX_STREAMS 4096u
 #define INFL_NOALLOC_MAX_SRC     (4u << 20)

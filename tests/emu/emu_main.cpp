@@ -230,11 +230,24 @@ static int main_resume(int argc, char **argv) {
     uint8_t *out = (uint8_t *)calloc(1, cap ? cap : 1);
     uint64_t fed = 0;
     do {
+      // the arena holds what earlier calls brought; this call's bytes come through `fresh`, its new output bytes
+      // (at most 24 of them: the cap is part of the test) and the state go to buffers of their own
+      const uint64_t before = fed;
       fed = fed + chunk < len ? fed + chunk : len;
-      uint8_t *in = (uint8_t *)malloc(fed ? fed : 1);
-      memcpy(in, src.data() + so[i], fed);
-      if (infl_launch_resume(in, (uint32_t)fed, out, (uint32_t)cap, flags & 1, &st, nullptr) != 0) return 3;
+      uint8_t *in = (uint8_t *)malloc(fed ? fed : 1), *fresh = (uint8_t *)malloc(fed - before ? fed - before : 1);
+      uint8_t  hout[24];
+      InflResume hst;
+      memset(&hst, 0xee, sizeof(hst));
+      memset(in, 0xee, fed ? fed : 1);
+      memcpy(in, src.data() + so[i], before);
+      memcpy(fresh, src.data() + so[i] + before, fed - before);
+      if (infl_launch_resume(in, (uint32_t)fed, out, (uint32_t)cap, flags & 1, &st, fresh, (uint32_t)before, hout,
+                             (uint32_t)sizeof(hout), &hst, nullptr) != 0) return 3;
       free(in);
+      free(fresh);
+      if (memcmp(&hst, &st, sizeof(st)) != 0 || st.reserved > st.pos) return 4;
+      const uint32_t fresh_out = st.pos - st.reserved < sizeof(hout) ? st.pos - st.reserved : (uint32_t)sizeof(hout);
+      if (memcmp(hout, out + st.reserved, fresh_out) != 0) return 4;
       if ((st.flags & INFL_RS_DONE) || (st.detail != INFL_D_NEED_INPUT && st.detail != INFL_D_OK)) break;
     } while (fed < len);
     status[i] = (st.flags & INFL_RS_DONE) ? 0 : st.detail;
@@ -276,7 +289,8 @@ static int main_png(char **argv) {
     memcpy(bi, in.data() + io[i], il);
     memset(bo, 0xee, ol);
     const uint64_t one_in[2] = {0, il}, one_out[2] = {0, ol};
-    if (infl_launch_png_unfilter(bi, one_in, &in_len[i], &in_status[i], bo, one_out, &geom[i], 1, &status[i], nullptr) != 0) return 3;
+    if (infl_launch_png_unfilter(bi, one_in, &in_len[i], &in_status[i], bo, one_out, &geom[i], 1, &status[i], nullptr,
+                                 il, ol) != 0) return 3;
     memcpy(out.data() + oo[i], bo, ol);
     free(bi);
     free(bo);
@@ -291,7 +305,9 @@ static int main_png(char **argv) {
 // emu_run <in.bin> <out.bin> gather 0 0: the device-side gather of input pieces.
 //   in : u64 n_pieces, u64 blob_len, u64 out_len, u64 piece_off[n], u64 piece_dst[n], u32 piece_len[n], blob bytes
 //   out: the gathered arena (out_len bytes, 0xee where nothing was written)
-// Blob and arena have their exact sizes, so that AddressSanitizer sees any access outside them.
+//        followed by i32 piece_status[n]
+// Blob and arena have their exact sizes, which the kernel is told, so that AddressSanitizer sees any access outside
+// them: a piece that reaches outside must be refused (status -1), not copied.
 static int main_gather(char **argv) {
   FILE *f = fopen(argv[1], "rb");
   if (!f) return 2;
@@ -305,9 +321,11 @@ static int main_gather(char **argv) {
   if (blob_len && fread(blob, 1, blob_len, f) != blob_len) return 2;
   fclose(f);
   memset(out, 0xee, out_len ? out_len : 1);
-  if (infl_launch_gather(blob, off.data(), len.data(), dst.data(), n, out, nullptr) != 0) return 3;
+  std::vector<int32_t> pst(n + 1, -99);
+  if (infl_launch_gather(blob, off.data(), len.data(), dst.data(), n, out, nullptr, blob_len, out_len, pst.data()) != 0) return 3;
   f = fopen(argv[2], "wb");
   fwrite(out, 1, out_len, f);
+  fwrite(pst.data(), 4, n, f);
   fclose(f);
   free(blob);
   free(out);

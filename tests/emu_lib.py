@@ -92,8 +92,9 @@ def run_png(filtered, geom, in_len=None, in_status=None, timeout=900):
     return [out[int(oo[i]):int(oo[i + 1])] for i in range(n)], status
 
 
-def run_gather(blob, piece_off, piece_len, piece_dst, out_len, timeout=600):
-    """infl_gather_kernel in the emulator: -> the gathered arena (uint8, 0xee where nothing was written)."""
+def run_gather(blob, piece_off, piece_len, piece_dst, out_len, timeout=600, want_status=False):
+    """infl_gather_kernel in the emulator, told the sizes of blob and arena: -> the gathered arena (uint8, 0xee where
+    nothing was written), with want_status also the per-piece status (0, or -1 for a piece outside blob or arena)."""
     n = len(piece_off)
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
@@ -107,4 +108,6 @@ def run_gather(blob, piece_off, piece_len, piece_dst, out_len, timeout=600):
         p = subprocess.run([EXE, fin, fout, "gather", "0", "0"], capture_output=True, timeout=timeout, env=env)
         if p.returncode != 0:
             raise RuntimeError("emu_run gather failed (%d): %s" % (p.returncode, p.stderr.decode()[-2000:]))
-        return np.fromfile(fout, dtype=np.uint8)
+        raw = np.fromfile(fout, dtype=np.uint8)
+        out, st = raw[:out_len], raw[out_len:out_len + 4 * n].view(np.int32)
+        return (out, st) if want_status else out

@@ -45,3 +45,16 @@ def test_c_caller_decodes_the_golden_pairs(engine):
     assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
     assert "dropin ok" in p.stdout
     assert "139 file pairs" in p.stdout
+
+
+@pytest.mark.gpu
+def test_four_host_threads_on_distinct_streams(engine):
+    """tests/c_dropin/threads_check.c: four host threads, each looping infl_buf, infl_include + infl_many, infl_stream,
+    infl_batch and infl_batch_noalloc over the golden pairs on streams of its own; the program stops at the first result
+    that differs from the raw twin."""
+    exe = os.path.join(CDIR, "threads_check")
+    if not os.path.exists(exe):
+        _build()
+    p = subprocess.run([exe, DATA, "4", "2"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    assert "threads ok: 4 threads" in p.stdout

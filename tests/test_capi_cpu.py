@@ -68,6 +68,40 @@ def test_stream_with_no_data_is_ok(engine):
     engine.lib.infl_destroy(st)
 
 
+def test_stream_with_data_but_no_decode_yet_is_noop(engine):
+    """Data given with infl_include(), then infl_stream(NULL, 0) before any decode has begun: UNZ_NOOP
+    (stream.c:505-507); the bytes are still there for a later call.  Returns before any device is needed."""
+    buf = (C.c_uint8 * 16)()
+    st = engine.lib.infl_init(buf, 16, 0)
+    piece = (C.c_uint8 * 6).from_buffer_copy(bytes.fromhex("010100feff41"))
+    engine.lib.infl_include(st, piece, 6)
+    assert engine.lib.infl_stream(st, None, 0) == capi.UNZ_NOOP
+    assert engine.lib.infl_stream(st, None, 0) == capi.UNZ_NOOP
+    assert engine.lib.infl_output_pos(st) == 0
+    engine.lib.infl_reset_pool(st)
+    assert engine.lib.infl_stream(st, None, 0) == capi.UNZ_OK      # nothing there any more: "empty data"
+    engine.lib.infl_destroy(st)
+
+
+def test_page_pool_recycles_pages_across_streams(engine):
+    """Pages of destroyed streams go to later streams (the library's page pool): many generations of streams with
+    small pieces, each generation destroyed before the next; contents never mix (host bookkeeping only)."""
+    buf = (C.c_uint8 * 16)()
+    piece = (C.c_uint8 * 5000)()
+    for gen in range(6):
+        sts = [engine.lib.infl_init(buf, 16, 0) for _ in range(64)]
+        for k, st in enumerate(sts):
+            for j in range(10):
+                C.memset(piece, (gen * 7 + k + j) & 0xff, 5000)
+                engine.lib.infl_include(st, piece, 5000)
+        for st in sts[::2]:
+            engine.lib.infl_destroy(st)
+        for st in sts[1::2]:
+            engine.lib.infl_reset_pool(st)
+            engine.lib.infl_include(st, piece, 100)
+            engine.lib.infl_destroy(st)
+
+
 def test_no_device_fails_loudly_not_silently(engine):
     """Without a GPU the decode entry points report an error; nothing decodes on the CPU."""
     if engine.lib.infl_gpu_device_count() > 0:

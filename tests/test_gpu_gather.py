@@ -105,3 +105,72 @@ def test_png_files_uploaded_whole_gather_inflate_unfilter(engine):
         assert dst[a:a + caps[i]].tobytes() == want_f[i], i
         assert oracle.png_unfilter(want_f[i], *geom[i]) == (0, want_px[i])
         assert st[i] == 0 and out[i] == want_px[i], i
+
+
+def test_checked_calls_refuse_descriptors_outside_their_buffers(engine):
+    """infl_gather_dev_checked / infl_png_unfilter_dev_checked: a piece or an image whose descriptor reaches outside the
+    buffers whose sizes the caller gave is refused (status -1) and nothing of it is read or written; the others are done.
+    (The same descriptors were first run through the kernel source under AddressSanitizer: test_emulated_gather_of_pieces.)"""
+    lib = engine.lib
+    assert lib.infl_gpu_init(0) == 0
+    blob = np.arange(200, dtype=np.uint8)
+    po = np.array([3, 190, 1 << 40, 10, 20, (1 << 64) - 4, 100], dtype=np.uint64)
+    pl = np.array([20, 11, 4, 30, 17, 8, 0], dtype=np.uint32)
+    pd = np.array([1, 21, 30, 40, 48, 0, 64], dtype=np.uint64)
+    n = len(po)
+    bufs = [lib.infl_gpu_malloc(4096) for _ in range(6)]          # blob, off, len, dst, arena, piece status
+    try:
+        assert all(bufs)
+        arena = np.full(64, 0xEE, dtype=np.uint8)
+        for b, a in zip(bufs[:5], (blob, po, pl, pd, arena)):
+            assert lib.infl_gpu_upload(b, a.ctypes.data, a.nbytes) == 0
+        assert lib.infl_gather_dev_checked(bufs[0], blob.nbytes, bufs[1], bufs[2], bufs[3], n, bufs[4], 64, bufs[5], None) == 0
+        assert lib.infl_gpu_sync() == 0
+        st = np.zeros(n, dtype=np.int32)
+        assert lib.infl_gpu_download(st.ctypes.data, bufs[5], st.nbytes) == 0
+        assert lib.infl_gpu_download(arena.ctypes.data, bufs[4], 64) == 0
+        assert st.tolist() == [0, -1, -1, -1, -1, -1, 0]          # (an empty piece at the very end of both buffers is fine)
+        want = np.full(64, 0xEE, dtype=np.uint8)
+        want[1:21] = blob[3:23]
+        assert np.array_equal(arena, want)
+        # without a status array the refused pieces are skipped all the same
+        assert lib.infl_gather_dev_checked(bufs[0], blob.nbytes, bufs[1], bufs[2], bufs[3], n, bufs[4], 64, None, None) == 0
+        assert lib.infl_gpu_sync() == 0
+        assert lib.infl_gpu_download(arena.ctypes.data, bufs[4], 64) == 0 and np.array_equal(arena, want)
+    finally:
+        for b in bufs:
+            if b:
+                lib.infl_gpu_free(b)
+
+    # un-filter: image 1's input range and image 2's output range reach beyond the arenas
+    pixels, filtered, _ = wl.png_filtered(5, 16, 8, 4)
+    g = np.zeros((3, 4), dtype=np.uint32)
+    g[:, :3] = (8, 64, 4)
+    fl = len(filtered)
+    in_off = np.array([0, fl, 2 * fl + 5, 3 * fl + 5], dtype=np.uint64)      # image 1's range ends 5 bytes past its data ...
+    in_bytes = 3 * fl                                                       # ... and image 2's past the arena
+    out_off = np.array([0, 512, 1024, 1536], dtype=np.uint64)
+    out_bytes = 1500                                                        # image 2's output does not fit
+    data = np.frombuffer(filtered * 3, dtype=np.uint8)
+    bufs = [lib.infl_gpu_malloc(8192) for _ in range(6)]                    # in, in_off, out, out_off, geom, status
+    try:
+        assert all(bufs)
+        for b, a in ((bufs[0], data), (bufs[1], in_off), (bufs[3], out_off), (bufs[4], g)):
+            assert lib.infl_gpu_upload(b, a.ctypes.data, a.nbytes) == 0
+        assert lib.infl_png_unfilter_dev_checked(bufs[0], in_bytes, bufs[1], None, None, bufs[2], out_bytes, bufs[3],
+                                                 bufs[4], 3, bufs[5], None) == 0
+        assert lib.infl_gpu_sync() == 0
+        st = np.zeros(3, dtype=np.int32)
+        out = np.zeros(512, dtype=np.uint8)
+        assert lib.infl_gpu_download(st.ctypes.data, bufs[5], 12) == 0
+        assert lib.infl_gpu_download(out.ctypes.data, bufs[2], 512) == 0
+        assert st.tolist() == [0, 0, -1] and out.tobytes() == pixels
+        assert lib.infl_png_unfilter_dev_checked(bufs[0], 2 * fl + 4, bufs[1], None, None, bufs[2], 4096, bufs[3],
+                                                 bufs[4], 3, bufs[5], None) == 0
+        assert lib.infl_gpu_sync() == 0
+        assert lib.infl_gpu_download(st.ctypes.data, bufs[5], 12) == 0
+        assert st.tolist() == [0, -1, -1]
+    finally:
+        for b in bufs:
+            if b:
+                lib.infl_gpu_free(b)

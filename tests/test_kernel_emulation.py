@@ -468,6 +468,13 @@ def test_emulated_gather_of_pieces():
     out = emu_lib.run_gather(bytes(range(200)), [3, 50], [20, 17], [1, 40], 64)
     want = bytearray(b"\xee" * 64); want[1:21] = bytes(range(3, 23)); want[40:57] = bytes(range(50, 67))
     assert out.tobytes() == bytes(want)
+    # pieces whose descriptors reach outside the blob or the arena (the kernel is told both sizes) are refused whole:
+    # source past the end, source offset far outside, target past the end, offset + length overflowing 64 bits
+    out, st = emu_lib.run_gather(bytes(range(200)), [3, 190, 1 << 40, 10, 20, (1 << 64) - 4], [20, 11, 4, 30, 17, 8],
+                                 [1, 21, 30, 40, 48, 0], 64, want_status=True)
+    assert st.tolist() == [0, -1, -1, -1, -1, -1]
+    want = bytearray(b"\xee" * 64); want[1:21] = bytes(range(3, 23))
+    assert out.tobytes() == bytes(want)
 
 
 def test_emulated_serial_passes_alone_match_shapes(oracle):

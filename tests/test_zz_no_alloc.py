@@ -46,6 +46,8 @@ def test_noalloc_matches_infl_batch_twice_in_a_row():
     assert rc == 0
     _same(want, (dst, status, outlen), dst_off)
     assert (status == 0).sum() >= 195 and (status != 0).sum() >= 2
+    tails1 = [dst[int(dst_off[i]) + int(outlen[i]):int(dst_off[i + 1])] for i in range(len(caps))]
+    assert all((t == 0).all() for t in tails1) and sum(t.size for t in tails1) > 1000   # failed streams: all of their share
 
     # second call right behind it, smaller, other data: nothing of the first call shows through
     raws2 = [wl.text_stream(1000 + i, 900 + 11 * i) for i in range(37)]
@@ -56,6 +58,30 @@ def test_noalloc_matches_infl_batch_twice_in_a_row():
     assert rc2 == 0 and (st2 == 0).all()
     _same(want2, (dst2, st2, ol2), do2)
     assert dst2[: int(do2[-1])].tobytes() == b"".join(raws2)
+
+    # third call: streams that fail where the first call's plain text lay: their share comes back as zeros
+    comps3 = [c[: len(c) // 3] for c in comps2]
+    src3, so3, do3 = wl.pack(comps3, [len(r) + 100 for r in raws2])
+    rc3, dst3, st3, ol3 = _noalloc(eng, src3, so3, do3, 0)
+    assert rc3 == 0 and (st3 != 0).all() and (ol3 == 0).all()
+    assert (dst3[: int(do3[-1])] == 0).all()
+
+
+def test_noalloc_refuses_offsets_that_decrease():
+    eng = capi.load()
+    assert eng.lib.infl_gpu_init(0) == 0
+    comp = wl.deflate(b"abc" * 10)
+    src, so, do = wl.pack([comp] * 4, [64] * 4)
+    bad = so.copy()
+    bad[2] = bad[1] - 1
+    rc, _, status, _ = _noalloc(eng, src, bad, do, 1)
+    assert rc == capi.UNZ_ERR and (status == -99).all()
+    bad = do.copy()
+    bad[3], bad[2] = bad[2], bad[3]
+    rc, _, status, _ = _noalloc(eng, src, so, bad, 1)
+    assert rc == capi.UNZ_ERR and (status == -99).all()
+    rc, _, status, outlen = _noalloc(eng, src, so, do, 1)
+    assert rc == 0 and (status == 0).all() and (outlen == 30).all()
 
 
 def test_noalloc_rejects_what_exceeds_the_fixed_workspace():
