@@ -1926,6 +1926,7 @@ __device__ __forceinline__ int block_loop(R &r, uint8_t *dst, uint32_t &pos, uin
         note[1] = 0;
         note[2] = pos;
         note[3] = 1;
+        note[4] = pos;                               // (the block's own start, for callers without an inpos array)
       }
     }
     if (r.n < 3) return INFL_D_NEED_INPUT;
@@ -2185,7 +2186,7 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1) 
     parp = &par;
   }
   if constexpr (MODE == 5) {
-    __shared__ uint32_t note_buf[4];
+    __shared__ uint32_t note_buf[5];
     note = note_buf;
   }
 
@@ -2207,8 +2208,7 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1) 
       resume     = true;
       resume_pos = outlen[i];
       resume_hdr = (uint32_t)detail[i];
-      if (inpos) resume_bit = inpos[i];
-      else __builtin_memcpy(&resume_bit, dst + dst_off[i] + resume_pos, 4);   // parked behind the output so far
+      resume_bit = inpos ? inpos[i] : 0u;            // (without an inpos array: the block's first symbol)
     }
     group_sync();                                    // every lane has looked before one of them writes the result
     if (MODE == 2 && mark == INFL_STATUS_DEFERRED_DONE) {            // finished by the windowed serial pass
@@ -2251,16 +2251,13 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1) 
                                          nullptr, lig, gshift, out, pos, cur);
   }
   if constexpr (MODE == 5) {
-    // Three numbers tell the last pass where to take the stream up again: outlen[i], detail[i] and inpos[i]; without
-    // an inpos array the third one is parked in the four bytes behind the output so far (a failing stream's output
-    // area holds nothing a caller may rely on), if there are four.  Anything else leaves the mark as it is.
-    if (lig == 0 && rc != INFL_D_OK && rc != INFL_D_NOFIT && rc != INFL_D_INTERNAL && note[3] && detail != nullptr &&
-        (inpos != nullptr || (uint32_t)(d1 - d0) - note[2] >= 4u)) {
-      const uint32_t bit = note[1];
-      outlen[i] = note[2];
+    // Three numbers tell the last pass where to take the stream up again: outlen[i], detail[i] and inpos[i].  A
+    // caller without an inpos array gives room for two: the last pass then goes on from the first symbol of the
+    // block in hand (nothing is ever parked in the caller's output area).  Anything else leaves the mark as it is.
+    if (lig == 0 && rc != INFL_D_OK && rc != INFL_D_NOFIT && rc != INFL_D_INTERNAL && note[3] && detail != nullptr) {
+      outlen[i] = inpos ? note[2] : note[4];
       detail[i] = (int32_t)note[0];
-      if (inpos) inpos[i] = bit;
-      else __builtin_memcpy(dst + d0 + note[2], &bit, 4);
+      if (inpos) inpos[i] = note[1];
       status[i] = INFL_STATUS_DEFERRED_RESUME;
     }
     return;
@@ -3103,7 +3100,8 @@ extern "C" int infl_launch_parallel_small(const void *src, const uint64_t *src_o
 //            (anything malformed or out of space, tables too large for the compact format,
 //            tiny streams) goes through the two serial passes of variant 1 (three launches).
 // variant 3: diagnostic: the parallel pass alone; deferred streams keep INFL_STATUS_DEFERRED.
-// variant 4: diagnostic: the parallel pass and the serial pass behind it; what they leave keeps its mark.
+// variant 4: diagnostic: the parallel pass and the serial pass behind it; what they leave keeps its mark, and a stream
+//            the windowed serial pass finished keeps INFL_STATUS_DEFERRED_DONE (only the last pass turns it into 0).
 // variant 5: the two serial passes of variant 2 alone, for every stream (variant 1 with the second pass's own kernel
 //            for 8 and 16 lanes per stream, which shares a window's marked streams out among its wavefronts).
 extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,

@@ -656,13 +656,62 @@ typedef struct {
   size_t          lo, hi;
   int32_t        *status;
   uint32_t       *outlen;
+  int             per_call_objects;
 } job_t;
+
+/* What infl_buf() does around the decode when it is called as it stands, one call per stream
+   (include/defl/infl.h:125-145): infl_init allocates a zeroed stream object (infl.c:1677-1695;
+   src/common.h:150-188: a pool of 1024 chunk-struct pointers, 32 page pointers, bit state, streaming
+   state and two recp/huff tables whose size is not known here: 9 KiB stands for it), infl_include
+   copies an input of at most 8 KiB into a fresh 64-byte aligned 32 KiB page (mem.c:35-78, 135-151)
+   and otherwise allocates a chunk node (mem.c:185-201), infl_destroy walks the 32 + 1024 pool slots
+   and frees (mem.c:331-361).  The other pattern the reference offers, one stream object reset
+   between inputs (mem.c:257-275), has none of this per stream and is what the plain batch driver
+   times. */
+#define ORACLE_STREAM_OBJECT_BYTES 9216u
+static const uint8_t *
+as_is_begin(const uint8_t *src, uint32_t len, void **obj, void **page) {
+  *obj  = calloc(1, ORACLE_STREAM_OBJECT_BYTES);
+  *page = NULL;
+  if (len <= 8192u) {
+    if (posix_memalign(page, 64, 32768) != 0) *page = NULL;
+    if (*page) {
+      memcpy(*page, src, len);
+      return (const uint8_t *)*page;
+    }
+  } else {
+    *page = calloc(1, 64);                        /* the borrowed chunk's node */
+  }
+  return src;
+}
+static void
+as_is_end(void *obj, void *page) {
+  if (obj) {
+    volatile const uintptr_t *slots = (volatile const uintptr_t *)obj;
+    uintptr_t                 any = 0;
+    for (unsigned k = 0; k < 32u + 1024u; k++) any |= slots[k];   /* the walk over the pool slots */
+    (void)any;
+  }
+  free(page);
+  free(obj);
+}
 
 static void *
 batch_worker(void *arg) {
   job_t *j = (job_t *)arg;
   for (size_t i = j->lo; i < j->hi; i++) {
     uint32_t out = 0;
+    if (j->per_call_objects) {
+      void          *obj, *page;
+      const uint32_t len = (uint32_t)(j->src_off[i + 1] - j->src_off[i]);
+      const uint8_t *in  = as_is_begin(j->src + j->src_off[i], len, &obj, &page);
+      j->status[i] = obj ? oracle_infl(in, len, j->dst + j->dst_off[i],
+                                       (uint32_t)(j->dst_off[i + 1] - j->dst_off[i]), j->flags, &out)
+                         : ORACLE_ERR;
+      as_is_end(obj, page);
+      j->outlen[i] = out;
+      continue;
+    }
     j->status[i] = oracle_infl(j->src + j->src_off[i],
                                (uint32_t)(j->src_off[i + 1] - j->src_off[i]),
                                j->dst + j->dst_off[i],
@@ -673,10 +722,27 @@ batch_worker(void *arg) {
   return NULL;
 }
 
+static int
+batch_run(const uint8_t *src, const uint64_t *src_off, uint8_t *dst, const uint64_t *dst_off, int flags,
+          size_t n, int32_t *status, uint32_t *outlen, int nthreads, int per_call_objects);
+
 int
 oracle_infl_batch(const uint8_t *src, const uint64_t *src_off, uint8_t *dst,
                   const uint64_t *dst_off, int flags, size_t n, int32_t *status,
                   uint32_t *outlen, int nthreads) {
+  return batch_run(src, src_off, dst, dst_off, flags, n, status, outlen, nthreads, 0);
+}
+
+int
+oracle_infl_batch_as_is(const uint8_t *src, const uint64_t *src_off, uint8_t *dst,
+                        const uint64_t *dst_off, int flags, size_t n, int32_t *status,
+                        uint32_t *outlen, int nthreads) {
+  return batch_run(src, src_off, dst, dst_off, flags, n, status, outlen, nthreads, 1);
+}
+
+static int
+batch_run(const uint8_t *src, const uint64_t *src_off, uint8_t *dst, const uint64_t *dst_off, int flags,
+          size_t n, int32_t *status, uint32_t *outlen, int nthreads, int per_call_objects) {
   pthread_t *th;
   job_t     *jobs;
 
@@ -689,7 +755,7 @@ oracle_infl_batch(const uint8_t *src, const uint64_t *src_off, uint8_t *dst,
   for (int t = 0; t < nthreads; t++) {
     jobs[t] = (job_t){src, src_off, dst, dst_off, flags,
                       n * (size_t)t / (size_t)nthreads,
-                      n * (size_t)(t + 1) / (size_t)nthreads, status, outlen};
+                      n * (size_t)(t + 1) / (size_t)nthreads, status, outlen, per_call_objects};
     if (nthreads == 1) batch_worker(&jobs[t]);
     else pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
   }

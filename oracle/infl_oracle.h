@@ -41,6 +41,13 @@ int oracle_infl_batch(const uint8_t *src, const uint64_t *src_off, uint8_t *dst,
                       const uint64_t *dst_off, int flags, size_t n, int32_t *status,
                       uint32_t *outlen, int nthreads);
 
+/* The same decode with, around every stream, the allocations and the copy the reference's infl_buf() makes when
+   it is called once per stream as it stands (include/defl/infl.h:125-145); the plain driver above corresponds to
+   the reference's other pattern, one stream object reset between inputs (src/infl/mem.c:257-275).  For timing. */
+int oracle_infl_batch_as_is(const uint8_t *src, const uint64_t *src_off, uint8_t *dst,
+                            const uint64_t *dst_off, int flags, size_t n, int32_t *status,
+                            uint32_t *outlen, int nthreads);
+
 /* observer called for every match decoded (NULL = off) */
 void oracle_set_match_hook(void (*hook)(unsigned pos, unsigned len, unsigned dist));
 

@@ -28,6 +28,8 @@ class Oracle:
         lib.oracle_infl_batch.restype = C.c_int
         lib.oracle_infl_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        lib.oracle_infl_batch_as_is.restype = C.c_int
+        lib.oracle_infl_batch_as_is.argtypes = lib.oracle_infl_batch.argtypes
         lib.oracle_table_build.restype = C.c_int
         lib.oracle_table_build.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.c_void_p, C.c_uint,
                                            C.c_uint, C.c_uint, C.c_int]
@@ -51,8 +53,9 @@ class Oracle:
         return rc, pos.value, bytes(dbuf[:pos.value]), detail.value
 
     def infl_batch(self, src: np.ndarray, src_off: np.ndarray, dst_off: np.ndarray, flags: int = 0,
-                   nthreads: int = 8):
-        """src: uint8 arena, offsets uint64[n+1] -> (dst arena, status int32[n], outlen uint32[n])"""
+                   nthreads: int = 8, as_is: bool = False):
+        """src: uint8 arena, offsets uint64[n+1] -> (dst arena, status int32[n], outlen uint32[n]).
+        as_is: with the per-call allocations of the reference's infl_buf() around every stream (for timing)."""
         n = len(src_off) - 1
         src = np.ascontiguousarray(src, dtype=np.uint8)
         src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
@@ -60,9 +63,9 @@ class Oracle:
         dst = np.zeros(max(1, int(dst_off[-1])), dtype=np.uint8)
         status = np.zeros(max(1, n), dtype=np.int32)
         outlen = np.zeros(max(1, n), dtype=np.uint32)
-        rc = self.lib.oracle_infl_batch(src.ctypes.data, src_off.ctypes.data, dst.ctypes.data,
-                                        dst_off.ctypes.data, flags, n, status.ctypes.data,
-                                        outlen.ctypes.data, nthreads)
+        fn = self.lib.oracle_infl_batch_as_is if as_is else self.lib.oracle_infl_batch
+        rc = fn(src.ctypes.data, src_off.ctypes.data, dst.ctypes.data, dst_off.ctypes.data, flags, n,
+                status.ctypes.data, outlen.ctypes.data, nthreads)
         assert rc == 0
         return dst, status[:n], outlen[:n]
 

@@ -8,6 +8,7 @@ import zlib
 
 import pytest
 
+import workloads as wl
 from tests import oracle_lib as ol
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -138,3 +139,12 @@ def test_truncation_never_ok_and_mutations_match_zlib(oracle):
             # a stream zlib accepts in full is a valid stream: the reference accepts it too
             assert rc == ol.OK
     assert agree > 0
+
+
+def test_text_generator_gathered_equals_joined():
+    """The benchmark's text generator builds a stream with array operations; the definition is the plain join of
+    words and separators.  Same random draws, same bytes, at sizes from nothing to 256 KiB."""
+    gen = wl.TextGen()
+    for i, size in [(0, 65536), (1, 65536), (77, 1024), (5, 3), (9, 0), (1000, 262144), (31, 50000), (5000, 128), (12, 1)]:
+        assert gen.make(i, size) == gen.make_joined(i, size), (i, size)
+    assert wl.text_stream(3, 4096) == gen.make_joined(3, 4096)

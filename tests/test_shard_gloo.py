@@ -82,6 +82,56 @@ def _bench_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _bench_main_worker(rank, world, port, outdir, extra):
+    """bench.main() itself as rank `rank` of `world`, the way the launcher starts it (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in the environment), with the decode answered by the CPU oracle on CPU tensors (DEFL_BENCH_STUB=1: the
+    rehearsal switch of bench.py) and gloo as the backend.  Descriptor 1 goes to a file: the result line."""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world), "DEFL_BENCH_STUB": "1",
+                       "OMP_NUM_THREADS": "2"})
+    fd = os.open(os.path.join(outdir, "rank%d.out" % rank), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.dup2(fd, 1)
+    import bench
+    bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1"] + extra)
+
+
+def _run_bench_main(world, extra, tmp_path):
+    import json
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_main_worker, args=(r, world, port, str(tmp_path), extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    lines = [open(os.path.join(str(tmp_path), "rank%d.out" % r)).read().strip() for r in range(world)]
+    assert all(not x for x in lines[1:])                       # only rank 0 prints
+    assert len(lines[0].splitlines()) == 1                     # and exactly one line
+    return json.loads(lines[0])
+
+
+def test_world2_bench_main_end_to_end_weak(tmp_path):
+    """The launch path of an N-GPU run executed end to end with world 2 on the CPU: argument handling, process group,
+    barriers around the timed steps, parity gate, all_gather of the per-rank figures, one JSON line from rank 0 with
+    the CPU baseline in it."""
+    r = _run_bench_main(2, ["--streams", "96", "--pool", "24"], tmp_path)
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 2
+    assert r["config"]["streams_total"] == 192 and r["config"]["distinct_streams"] == 48
+    assert r["config"]["bit_exact_vs_oracle"] is True and len(r["config"]["per_rank_ms_per_step"]) == 2
+    assert "REHEARSAL" in r["config"] and r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
+    assert abs(r["value"] - 192 * 65536 * 2 / (r["ms_per_step"] * 2e-3) / 1e6) < 0.01 * r["value"]
+
+
+def test_world2_bench_main_end_to_end_strong_mixed(tmp_path):
+    """The same for the sharded mixed-size configuration: one batch ordered by falling size, cut by shard.partition."""
+    r = _run_bench_main(2, ["--workload", "mixed", "--scaling", "strong", "--streams", "120", "--pool", "12",
+                            "--no-cpu-baseline"], tmp_path)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["streams_total"] == 120
+    assert abs(sum(r["config"]["partition_cost_share"]) - 1.0) < 1e-3
+    assert r["config"]["per_rank_load_imbalance"] < 1.5 and "cpu_baseline" not in r
+
+
 def test_world2_bench_strong_scaling_path():
     world = 2
     ctx = mp.get_context("spawn")

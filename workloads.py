@@ -48,8 +48,10 @@ class TextGen:
         self.cdf = np.cumsum(p / p.sum())
         self.seps = [b" ", b", ", b". ", b"\n"]
         self.sep_cdf = np.cumsum([0.82, 0.08, 0.07, 0.03])
+        self._table = None
 
-    def make(self, i: int, size: int) -> bytes:
+    def make_joined(self, i: int, size: int) -> bytes:
+        """The definition: words and separators joined one after the other (slow: a Python loop over the words)."""
         rng = np.random.default_rng(stream_seed(i))
         nwords = size // 3 + 8
         wi = np.searchsorted(self.cdf, rng.random(nwords))
@@ -59,6 +61,39 @@ class TextGen:
         while len(out) < size:
             out += out
         return out[:size]
+
+    def _token_table(self):
+        """All words and separators back to back, with every token's start and length (tokens 0 .. V-1 are the
+        words, V .. V+3 the separators)."""
+        toks = self.words + self.seps
+        lens = np.array([len(t) for t in toks], dtype=np.int64)
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        return np.frombuffer(b"".join(toks), dtype=np.uint8), starts, lens
+
+    def make(self, i: int, size: int) -> bytes:
+        """The same bytes as make_joined(), gathered with array operations (the same random draws in the same order;
+        the benchmark builds thousands of these streams per run)."""
+        if self._table is None:
+            self._table = self._token_table()
+        blob, tstart, tlen = self._table
+        v = len(self.words)
+        rng = np.random.default_rng(stream_seed(i))
+        nwords = size // 3 + 8
+        wi = np.minimum(np.searchsorted(self.cdf, rng.random(nwords)), v - 1)
+        si = np.minimum(np.searchsorted(self.sep_cdf, rng.random(nwords)), 3)
+        tok = np.empty(2 * nwords, dtype=np.int64)
+        tok[0::2] = wi
+        tok[1::2] = v + si
+        lens = tlen[tok]
+        ends = np.cumsum(lens)
+        total = int(ends[-1])
+        k = min(len(tok), int(np.searchsorted(ends, size)) + 1)         # tokens that reach the first `size` bytes
+        begin = ends[:k] - lens[:k]
+        idx = np.repeat(tstart[tok[:k]] - begin, lens[:k]) + np.arange(int(ends[k - 1]), dtype=np.int64)
+        out = blob[idx]
+        if total < size:                                                # (the joined text doubled until it is long enough)
+            out = np.resize(out, size)
+        return out[:size].tobytes()
 
 
 _textgen = None
