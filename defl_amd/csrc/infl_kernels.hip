@@ -1380,6 +1380,26 @@ __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
 }
 
+// Two 16-bit values to a register, worked on with the packed integer instructions (v_pk_sub_u16, v_pk_ashrrev_i16);
+// a portable form serves compilers without vector extensions (the host-side emulation of the test suite).
+#if defined(__clang__)
+typedef unsigned short pk_u16x2 __attribute__((ext_vector_type(2)));
+typedef short          pk_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (pk_u16x2)(__builtin_bit_cast(pk_u16x2, a) - __builtin_bit_cast(pk_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sign16(uint32_t a) {           // 0xffff where a half has its top bit set, else 0
+  return __builtin_bit_cast(uint32_t, (pk_i16x2)(__builtin_bit_cast(pk_i16x2, a) >> (pk_i16x2)(15)));
+}
+#else
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
+  return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16);
+}
+__device__ __forceinline__ uint32_t pk_sign16(uint32_t a) {
+  return ((a & 0x8000u) ? 0xffffu : 0u) | ((a & 0x80000000u) ? 0xffff0000u : 0u);
+}
+#endif
+
 // 32 bits of the stream from bit `rel` of the column on (see ParLds)
 __device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t rel) {
   static_assert(PAR_ROWS <= 16, "the row index is masked to four bits");
@@ -1786,33 +1806,40 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
       group_sync();
       PROF_MARK(4);
 
-      // 5a. expand: every byte finds the head at or before it (a maximum scan over the 64 lanes
-      //     of a chunk, the last head of earlier chunks carried along) and becomes a literal, an
-      //     index of an earlier byte of the group, or LK_EXT | how far before it.
+      // 5a. expand: every byte finds the head at or before it and becomes a literal, an index of an earlier
+      //     byte of the group, or LK_EXT | how far before it.  A lane takes four consecutive entries of a
+      //     256-entry batch: the last head among its four goes into a maximum scan over the lanes (key =
+      //     lane : head, so the maximum over the lanes below is the nearest head before the lane's entries,
+      //     with its value; the last head of earlier batches is seeded into lane 0), the four entries then take
+      //     their heads one from the other, and the link arithmetic runs on two entries to a register.
       {
-        // The key of a head is lane : head, so the maximum over the lanes at or below a byte is
-        // the nearest head with its value; lane 0 carries the last head of the chunks before in.
-        // Entries behind the end of the group (the batch's padding) become copies of the last
-        // symbol's links: valid, never written out.
+        // A byte inside a match with head LK_EXT | (dd - 1) at entry i becomes i - dd where that is an entry of
+        // the group, else LK_EXT | (dd - i - 1).  In 16 bits: t = i - dd = (i + 0x7fff) - head, and a negative t
+        // with its low 15 bits flipped is LK_EXT | (-t - 1).  Entries behind the end of the group (the batch's
+        // padding) become copies of the last symbol's links: valid, never written out.
+        constexpr uint32_t K15 = 0x7fff7fffu;
         uint32_t carry = 0;
+        uint32_t at01  = ((4u * (uint32_t)lane + 1u + 0x7fffu) << 16) | (4u * (uint32_t)lane + 0x7fffu);   // i + 0x7fff, entries 0 and 1
         for (uint32_t base = 0; base < total_out; base += 256) {
-          uint32_t h[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) h[u] = P.link[base + 64u * u + (uint32_t)lane];   // 0 behind the end
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t i    = base + 64u * u + (uint32_t)lane;
-            const uint32_t seed = lane == 0 ? carry : 0u;
-            const uint32_t s    = wave_scan_max(h[u] ? ((uint32_t)lane << 16) | h[u] : seed);
-            const uint32_t desc = s & 0xffffu;
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)s, 63) & 0xffffu;
-            uint32_t out = desc;
-            if (desc >= LK_EXT) {                   // a match: distance dd = desc - LK_EXT + 1
-              const uint32_t dd = desc - (LK_EXT - 1u);
-              out = dd <= i ? i - dd : (LK_EXT - 1u) + dd - i;
-            }
-            P.link[i] = (uint16_t)out;
-          }
+          uint2 q;
+          __builtin_memcpy(&q, &P.link[base + 4u * (uint32_t)lane], 8);
+          const uint32_t h0 = q.x & 0xffffu, h1 = q.x >> 16, h2 = q.y & 0xffffu, h3 = q.y >> 16;
+          uint32_t last = h2 ? h2 : h1 ? h1 : h0;
+          last          = h3 ? h3 : last;
+          const uint32_t seed = lane == 0 ? carry : 0u;
+          const uint32_t s    = wave_scan_max(last ? ((uint32_t)lane << 16) | last : seed);
+          carry = (uint32_t)__builtin_amdgcn_readlane((int)s, 63) & 0xffffu;
+          // the nearest head before the lane's entries: the scan's result one lane down
+          const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)seed, (int)s, 0x138 /* wave_shr:1 */, 0xf, 0xf, false) & 0xffffu;
+          const uint32_t c0 = h0 ? h0 : before, c1 = h1 ? h1 : c0, c2 = h2 ? h2 : c1, c3 = h3 ? h3 : c2;
+          const uint32_t c01 = (c1 << 16) | c0, c23 = (c3 << 16) | c2;
+          const uint32_t t01 = pk_sub16(at01, c01), t23 = pk_sub16(at01 + 0x00020002u, c23);
+          const uint32_t o01 = t01 ^ (pk_sign16(t01) & K15), o23 = t23 ^ (pk_sign16(t23) & K15);
+          const uint32_t m01 = pk_sign16(c01), m23 = pk_sign16(c23);            // a match head (LK_EXT is the top bit)
+          q.x = (o01 & m01) | (c01 & ~m01);
+          q.y = (o23 & m23) | (c23 & ~m23);
+          __builtin_memcpy(&P.link[base + 4u * (uint32_t)lane], &q, 8);
+          at01 += 0x01000100u;                       // the next batch: 256 entries on
         }
       }
       group_sync();
@@ -1864,8 +1891,16 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               const uint32_t v    = (uint32_t)(q >> (16 * k)) & 0xffffu;
+#if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 1     // (diagnostic, wrong output: every fetch hits the line before the group)
+              const uint32_t back = pos ? 1u : 0u;
+#else
               const uint32_t back = v >= LK_EXT ? v - (LK_EXT - 1u) : (pos ? 1u : 0u);
+#endif
+#if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 2     // (diagnostic, wrong output: no fetch at all)
+              g[k] = back;
+#else
               g[k] = dst[pos - back];
+#endif
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {

@@ -14,6 +14,7 @@ struct dim3 {
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
 typedef void *hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
