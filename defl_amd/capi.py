@@ -25,7 +25,7 @@ EXPORTS = [
     "infl_many", "infl_gpu_malloc", "infl_gpu_free", "infl_gpu_upload", "infl_gpu_download",
     "infl_gpu_sync", "infl_gpu_set_lanes_per_stream", "infl_gpu_set_table_variant",
     "infl_batch_noalloc", "infl_batch_dev_checked", "infl_batch_checked", "infl_png_unfilter_dev", "infl_gather_dev",
-    "infl_gather_dev_checked", "infl_png_unfilter_dev_checked",
+    "infl_gather_dev_checked", "infl_png_unfilter_dev_checked", "infl_batch_dev_sorted",
 ]
 
 
@@ -122,6 +122,7 @@ class Engine:
             "infl_gpu_device_count": (i32, []),
             "infl_batch_dev": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp]),
             "infl_batch_dev_detail": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp, vp]),
+            "infl_batch_dev_sorted": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp, vp]),
             "infl_batch": (i32, [vp, vp, vp, vp, i32, sz, vp, vp]),
             "infl_batch_noalloc": (i32, [vp, vp, vp, vp, i32, sz, vp, vp]),
             "infl_batch_dev_checked": (i32, [vp, vp, vp, vp, i32, sz, vp, vp, vp, vp, vp]),

@@ -88,6 +88,16 @@ int infl_launch_batch(const void *src, const uint64_t *src_off, void *dst,
                       uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
                       int variant, void *mirror, void *stream, const uint32_t *skip);
 
+/* infl_launch_batch with the order in which the parallel pass's workgroups take the streams (n indices in
+   device memory, may be NULL), as infl_launch_order leaves it at (uint32_t *)work + 256. */
+int infl_launch_batch_ordered(const void *src, const uint64_t *src_off, void *dst,
+                              const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
+                              uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
+                              int variant, void *mirror, void *stream, const uint32_t *skip,
+                              const uint32_t *order);
+#define INFL_ORDER_WORK_BYTES(n) (1024u + 4u * (size_t)(n))
+int infl_launch_order(const uint64_t *src_off, const uint64_t *dst_off, uint64_t n, void *work, void *stream);
+
 /* infl_launch_batch plus the integrity pass (see infl_batch_dev_checked in infl_batch.h);
    work = 8 * n bytes of device memory. */
 int infl_launch_checked(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,

@@ -32,7 +32,7 @@ struct Buf {
 // Workspace of the host-memory path, grown on demand and kept for reuse.
 // One set per device the process has used.
 struct Workspace {
-  Buf   src, dst, soff, doff, status, outlen, detail, inpos;   // device
+  Buf   src, dst, soff, doff, status, outlen, detail, inpos, order;   // device
   Buf   hdst, hmeta, hsrc;                               // pinned host staging: output bytes, the four result arrays, input
 };
 constexpr int MAX_DEV = 16;
@@ -44,6 +44,7 @@ constexpr int      kPipeSlices     = 16;               // at most this many slic
 constexpr int      kPipeStreams    = 4;                // slices in flight
 constexpr size_t   kPipeMinBytes   = 64u << 20;        // smaller batches are not sliced
 constexpr size_t   kPipeMinStreams = 256;              // a slice holds at least this many streams
+constexpr size_t   kOrderMinStreams = 4096;            // batches (or slices) of at least this many streams are put into size classes
 struct Pipe {
   hipStream_t st[kPipeStreams] = {}, up = nullptr;        // decode + download, in turn; uploads
   hipEvent_t  ev[kPipeSlices] = {}, evu[kPipeSlices] = {};  // slice downloaded; slice uploaded
@@ -227,6 +228,19 @@ int infl_batch_dev(const void *dev_src, const uint64_t *dev_src_off, void *dev_d
                            dev_outlen, nullptr, nullptr, g_lanes.load(), g_variant.load(), nullptr, hip_stream, nullptr);
 }
 
+// infl_batch_dev with the batch put into size classes first (a counting sort on the device), so that streams of
+// widely different sizes side by side do not slow the decode down.
+int infl_batch_dev_sorted(const void *dev_src, const uint64_t *dev_src_off, void *dev_dst,
+                          const uint64_t *dev_dst_off, int flags, size_t n, int32_t *dev_status,
+                          uint32_t *dev_outlen, void *dev_work, void *hip_stream) {
+  if (n == 0) return 0;
+  if (!dev_src_off || !dev_dst_off || !dev_status || !dev_outlen || !dev_work || n > 0xffffffffull) return -1;
+  if (infl_launch_order(dev_src_off, dev_dst_off, n, dev_work, hip_stream) != 0) return -1;
+  return infl_launch_batch_ordered(dev_src, dev_src_off, dev_dst, dev_dst_off, flags, n, dev_status, dev_outlen,
+                                   nullptr, nullptr, g_lanes.load(), g_variant.load(), nullptr, hip_stream, nullptr,
+                                   (const uint32_t *)dev_work + 256);
+}
+
 // Same with the per-stream detail codes (INFL_D_*); for tests and diagnosis.
 int infl_batch_dev_detail(const void *dev_src, const uint64_t *dev_src_off, void *dev_dst,
                           const uint64_t *dev_dst_off, int flags, size_t n, int32_t *dev_status,
@@ -320,6 +334,9 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
       !dev_reserve(w.detail, n * 4) || !dev_reserve(w.inpos, n * 4) ||
       !host_reserve(w.hdst, dst_bytes + 16) || !host_reserve(w.hmeta, 4 * n * 4))
     return -12;
+  // (room for the size-class order of a batch of many streams, or of each of its slices; the decode does without)
+  const bool have_order = n >= kOrderMinStreams && n <= 0xffffffffull &&
+                          dev_reserve(w.order, INFL_ORDER_WORK_BYTES(n) + 1024u * kPipeSlices);
 
   // Hand back exactly the bytes each stream produced; the rest of the caller's
   // destination is left untouched.
@@ -366,10 +383,14 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
       (void)hipGetLastError();
       return -1;
     }
-    if (infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p,
-                          flags, n, (int32_t *)w.status.p, (uint32_t *)w.outlen.p,
-                          detail ? (int32_t *)w.detail.p : nullptr, inpos ? (uint32_t *)w.inpos.p : nullptr,
-                          lanes, variant, w.hdst.p, st, nullptr) != 0) {
+    const uint32_t *order = nullptr;
+    if (have_order &&
+        infl_launch_order((const uint64_t *)w.soff.p, (const uint64_t *)w.doff.p, n, w.order.p, st) == 0)
+      order = (const uint32_t *)w.order.p + 256;
+    if (infl_launch_batch_ordered(w.src.p, (const uint64_t *)w.soff.p, w.dst.p, (const uint64_t *)w.doff.p,
+                                  flags, n, (int32_t *)w.status.p, (uint32_t *)w.outlen.p,
+                                  detail ? (int32_t *)w.detail.p : nullptr, inpos ? (uint32_t *)w.inpos.p : nullptr,
+                                  lanes, variant, w.hdst.p, st, nullptr, order) != 0) {
       (void)hipStreamSynchronize(st);                    // the uploads queued above still read the caller's buffers
       return -1;
     }
@@ -466,11 +487,18 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
     }
     ok &= hipEventRecord(pp.evu[nsl], pp.up) == hipSuccess;
     ok &= hipStreamWaitEvent(st, pp.evu[nsl], 0) == hipSuccess;
-    ok = ok && infl_launch_batch(w.src.p, (const uint64_t *)w.soff.p + lo, w.dst.p, (const uint64_t *)w.doff.p + lo,
-                                 flags, hi - lo, (int32_t *)w.status.p + lo, (uint32_t *)w.outlen.p + lo,
-                                 detail ? (int32_t *)w.detail.p + lo : nullptr,
-                                 inpos ? (uint32_t *)w.inpos.p + lo : nullptr, lanes, variant,
-                                 w.hdst.p, st, nullptr) == 0;
+    // (a slice of many streams is put into size classes first; slice k's counters and indices lie at 1024 k + 4 lo)
+    const uint32_t *order = nullptr;
+    if (ok && have_order && hi - lo >= kOrderMinStreams) {
+      uint8_t *work = (uint8_t *)w.order.p + 1024u * (size_t)nsl + 4u * lo;
+      if (infl_launch_order((const uint64_t *)w.soff.p + lo, (const uint64_t *)w.doff.p + lo, hi - lo, work, st) == 0)
+        order = (const uint32_t *)work + 256;
+    }
+    ok = ok && infl_launch_batch_ordered(w.src.p, (const uint64_t *)w.soff.p + lo, w.dst.p, (const uint64_t *)w.doff.p + lo,
+                                         flags, hi - lo, (int32_t *)w.status.p + lo, (uint32_t *)w.outlen.p + lo,
+                                         detail ? (int32_t *)w.detail.p + lo : nullptr,
+                                         inpos ? (uint32_t *)w.inpos.p + lo : nullptr, lanes, variant,
+                                         w.hdst.p, st, nullptr, order) == 0;
     const size_t cnt = (hi - lo) * 4;
     ok &= hipMemcpyAsync(hm + lo, (int32_t *)w.status.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;
     ok &= hipMemcpyAsync(hm + n + lo, (uint32_t *)w.outlen.p + lo, cnt, hipMemcpyDeviceToHost, st) == hipSuccess;

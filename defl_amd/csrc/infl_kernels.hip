@@ -2206,7 +2206,8 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1) 
                                                         int32_t *__restrict__ detail,
                                                         uint32_t *__restrict__ inpos,
                                                         uint8_t *__restrict__ mirror,
-                                                        const uint32_t *__restrict__ skip) {
+                                                        const uint32_t *__restrict__ skip,
+                                                        const uint32_t *__restrict__ order) {
   constexpr int  G    = 64 / T;                    // streams per wavefront
   // MODE 6 = MODE 3 for a batch too small to fill the device: wavefronts are to be had, and a short stream is through
   // the parallel decoder sooner than through the serial pass (85 us against 90 .. 170 us for 128 .. 384 bytes), so it
@@ -2229,9 +2230,12 @@ __global__ __launch_bounds__(64, (MODE == 3 || MODE == 5 || MODE == 6) ? 4 : 1) 
   const int      group  = lane / T;
   const int      lig    = lane % T;
   const int      gshift = group * T;
-  const uint64_t i      = (uint64_t)blockIdx.x * G + group;
+  const uint64_t slot   = (uint64_t)blockIdx.x * G + group;
 
-  if (i >= n) return;
+  if (slot >= n) return;
+  // `order` (may be null): the streams in the order the workgroups are to take them (by size class, see
+  // infl_order_* below): workgroups that start together then decode streams of similar length
+  const uint64_t i = order ? (uint64_t)order[slot] : slot;
   bool     resume = false;
   uint32_t resume_hdr = 0, resume_bit = 0, resume_pos = 0;
   if (MODE == 2 || MODE == 4 || MODE == 5) {
@@ -2404,10 +2408,11 @@ __global__ __launch_bounds__(64, 1) void infl_deferred_window_kernel(const uint8
 // out 0.5 % slower on the headline batch.
 extern "C" int infl_launch_parallel_small(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
                                           int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
-                                          uint32_t *inpos, void *mirror, void *stream, const uint32_t *skip) {
+                                          uint32_t *inpos, void *mirror, void *stream, const uint32_t *skip,
+                                          const uint32_t *order) {
   hipLaunchKernelGGL((defl::infl_batch_kernel<64, defl::CompactFmt, 6>), dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream,
                      (const uint8_t *)src, src_off, (uint8_t *)dst, dst_off, flags, n, status, outlen, detail, inpos,
-                     (uint8_t *)mirror, skip);
+                     (uint8_t *)mirror, skip, order);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 #else
@@ -3117,6 +3122,54 @@ __global__ __launch_bounds__(64) void infl_gather_kernel(const uint8_t *__restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Order of a batch by size class.  A batch whose neighbouring streams differ widely in size decodes a quarter
+// slower than the same streams with similar sizes side by side (1 KiB .. 256 KiB log-uniform, 262 144 streams:
+// 59.4 ms in no order, 43.1 ms counting-sorted into one class per doubling of a stream's compressed + decompressed
+// bytes, 42.0 ms with eight classes per doubling, 41.7 ms fully sorted).  A counting sort on the device gives the
+// parallel pass that order: classes by falling size (four per doubling), any order inside a class.  Results do not
+// depend on the order streams are decoded in.  work: ORDER_CLASSES counters, then n indices.
+// ---------------------------------------------------------------------------------------------
+constexpr int ORDER_CLASSES = 256;
+__device__ __forceinline__ uint32_t order_class(uint64_t cost) {
+  if (cost < 4) return ORDER_CLASSES - 1u - (uint32_t)cost;
+  const uint32_t lg = 63u - (uint32_t)__builtin_clzll(cost);             // 2 .. 63
+  const uint32_t c  = 4u * lg + (uint32_t)((cost >> (lg - 2)) & 3u);     // four classes per doubling: 8 .. 255
+  return ORDER_CLASSES - 1u - c;                                         // largest first
+}
+__global__ __launch_bounds__(256) void infl_order_clear_kernel(uint32_t *__restrict__ counters) {
+  counters[threadIdx.x] = 0;
+}
+__global__ __launch_bounds__(256) void infl_order_count_kernel(const uint64_t *__restrict__ src_off,
+                                                               const uint64_t *__restrict__ dst_off, uint64_t n,
+                                                               uint32_t *__restrict__ counters) {
+  __shared__ uint32_t local[ORDER_CLASSES];
+  local[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i < n) atomicAdd(&local[order_class((src_off[i + 1] - src_off[i]) + (dst_off[i + 1] - dst_off[i]))], 1u);
+  __syncthreads();
+  if (local[threadIdx.x]) atomicAdd(&counters[threadIdx.x], local[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void infl_order_scan_kernel(uint32_t *__restrict__ counters) {   // counts -> first slots
+  __shared__ uint32_t v[ORDER_CLASSES];
+  v[threadIdx.x] = counters[threadIdx.x];
+  __syncthreads();
+  uint32_t before = 0;
+  for (unsigned k = 0; k < threadIdx.x; k++) before += v[k];
+  counters[threadIdx.x] = before;
+}
+__global__ __launch_bounds__(256) void infl_order_place_kernel(const uint64_t *__restrict__ src_off,
+                                                               const uint64_t *__restrict__ dst_off, uint64_t n,
+                                                               uint32_t *__restrict__ counters,
+                                                               uint32_t *__restrict__ order) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i < n) {
+    const uint32_t c = order_class((src_off[i + 1] - src_off[i]) + (dst_off[i + 1] - dst_off[i]));
+    order[atomicAdd(&counters[c], 1u)] = (uint32_t)i;
+  }
+}
+
 }  // namespace defl
 
 #ifndef DEFL_LAUNCH_GROUP
@@ -3126,7 +3179,8 @@ __global__ __launch_bounds__(64) void infl_gather_kernel(const uint8_t *__restri
 #ifndef DEFL_SINGLE_UNIT
 extern "C" int infl_launch_parallel_small(const void *src, const uint64_t *src_off, void *dst, const uint64_t *dst_off,
                                           int flags, uint64_t n, int32_t *status, uint32_t *outlen, int32_t *detail,
-                                          uint32_t *inpos, void *mirror, void *stream, const uint32_t *skip);
+                                          uint32_t *inpos, void *mirror, void *stream, const uint32_t *skip,
+                                          const uint32_t *order);
 #endif
 
 // variant 0: reference-geometry tables only (one launch).
@@ -3143,6 +3197,17 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
                                  const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
                                  uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
                                  int variant, void *mirror, void *stream, const uint32_t *skip) {
+  return infl_launch_batch_ordered(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, lanes, variant,
+                                   mirror, stream, skip, nullptr);
+}
+
+// The same with `order` (may be null): the sequence in which the parallel pass's workgroups take the streams, made
+// by infl_launch_order.  The serial passes behind it work on what that pass marked, in index order.
+extern "C" int infl_launch_batch_ordered(const void *src, const uint64_t *src_off, void *dst,
+                                         const uint64_t *dst_off, int flags, uint64_t n, int32_t *status,
+                                         uint32_t *outlen, int32_t *detail, uint32_t *inpos, int lanes,
+                                         int variant, void *mirror, void *stream, const uint32_t *skip,
+                                         const uint32_t *order) {
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   auto s = (const uint8_t *)src;
@@ -3153,15 +3218,21 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
     DEFL_LAUNCH_GROUP(T);                                                                        \
     hipLaunchKernelGGL((defl::infl_batch_kernel<T, defl::FMT, MODE>),                            \
                        dim3((unsigned)((n + (64 / T) - 1) / (64 / T))), dim3(64), 0, st, s, src_off, \
-                       d, dst_off, flags, n, status, outlen, detail, inpos, m, skip);            \
+                       d, dst_off, flags, n, status, outlen, detail, inpos, m, skip,             \
+                       (MODE) == 3 ? order : (const uint32_t *)nullptr);                         \
   } while (0)
 #ifdef DEFL_SINGLE_UNIT            /* (the test suite's host-side emulation compiles everything as one unit) */
-#define LAUNCH_SMALL() LAUNCH(64, CompactFmt, 6)
+#define LAUNCH_SMALL()                                                                           \
+  do {                                                                                           \
+    DEFL_LAUNCH_GROUP(64);                                                                       \
+    hipLaunchKernelGGL((defl::infl_batch_kernel<64, defl::CompactFmt, 6>), dim3((unsigned)n), dim3(64), 0, st, s, \
+                       src_off, d, dst_off, flags, n, status, outlen, detail, inpos, m, skip, order); \
+  } while (0)
 #else
 #define LAUNCH_SMALL()                                                                                          \
   do {                                                                                                          \
     if (infl_launch_parallel_small(src, src_off, dst, dst_off, flags, n, status, outlen, detail, inpos, mirror, \
-                                   stream, skip) != 0)                                                          \
+                                   stream, skip, order) != 0)                                                   \
       return -1;                                                                                                \
   } while (0)
 #endif
@@ -3213,6 +3284,22 @@ extern "C" int infl_launch_batch(const void *src, const uint64_t *src_off, void 
 #undef LAUNCH_SMALL
 #undef LAUNCH_DEFERRED_PLAIN
 #undef LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Enqueues the counting sort of infl_order_*: work = INFL_ORDER_WORK_BYTES(n) bytes of device memory; the order is
+// left at (uint32_t *)work + 256.  n < 2^32.
+extern "C" int infl_launch_order(const uint64_t *src_off, const uint64_t *dst_off, uint64_t n, void *work, void *stream) {
+  if (n == 0) return 0;
+  if (!work || n > 0xffffffffull) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t   *counters = (uint32_t *)work, *order = counters + defl::ORDER_CLASSES;
+  const dim3  grid((unsigned)((n + 255) / 256));
+  DEFL_LAUNCH_GROUP(64);
+  hipLaunchKernelGGL(defl::infl_order_clear_kernel, dim3(1), dim3(256), 0, st, counters);
+  hipLaunchKernelGGL(defl::infl_order_count_kernel, grid, dim3(256), 0, st, src_off, dst_off, n, counters);
+  hipLaunchKernelGGL(defl::infl_order_scan_kernel, dim3(1), dim3(256), 0, st, counters);
+  hipLaunchKernelGGL(defl::infl_order_place_kernel, grid, dim3(256), 0, st, src_off, dst_off, n, counters, order);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

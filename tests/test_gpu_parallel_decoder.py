@@ -186,3 +186,46 @@ def test_differential_fuzz_many_rounds(engine, oracle, seed):
         streams.append(bytes(m))
         caps.append(rng.choice([len(raw), len(raw), len(raw) + 100, max(0, len(raw) - rng.randint(1, 5000))]))
     _check_batch(engine, oracle, streams, caps, 1, 16, "fuzz-%d" % seed, 2)
+
+
+@pytest.mark.parametrize("n", [1, 255, 257, 5000, 70001])
+def test_sorted_entry_point_gives_the_same_results(engine, oracle, n):
+    """infl_batch_dev_sorted (the batch put into size classes by a counting sort on the device before the decode) against
+    the oracle and against infl_batch_dev: streams of 0 bytes to 100 KiB in no order, damaged and truncated ones, stored
+    blocks and streams whose output does not fit among them; batch sizes around the sort kernels' block size."""
+    lib = engine.lib
+    rng = random.Random(4000 + n)
+    distinct = min(n, 600)
+    raws, comps, caps = [], [], []
+    for k in range(distinct):
+        size = int(2 ** rng.uniform(0, 16.6)) if k % 9 else 0
+        raw = wl.text_stream(7000 + k, size) if k % 5 else wl.stored_stream(k, size)[0]
+        comp = wl.deflate(raw) if k % 5 else wl.stored_stream(k, size)[1]
+        if k % 37 == 11 and len(comp) > 20:
+            comp = comp[: len(comp) // 2]
+        if k % 41 == 13 and len(comp) > 30:
+            bad = bytearray(comp); bad[len(bad) // 2] ^= 0x24; comp = bytes(bad)
+        raws.append(raw); comps.append(comp); caps.append(max(0, len(raw) - (3 if k % 53 == 17 else 0)))
+    pick = [rng.randrange(distinct) for _ in range(n)]
+    streams, cap = [comps[j] for j in pick], [caps[j] for j in pick]
+    src, src_off, dst_off = wl.pack(streams, cap)
+    want_dst, want_status, want_outlen = oracle.infl_batch(src, src_off, dst_off, 1)
+    b = engine.device_batch(src, src_off, dst_off)
+    work = lib.infl_gpu_malloc(1024 + 4 * n + 16)
+    try:
+        assert work
+        b.run(1, detail=False)
+        dst0, status0, outlen0, _ = b.results()
+        fill = np.full(max(1, b.dst_bytes), 0xA5, dtype=np.uint8)
+        assert lib.infl_gpu_upload(b.d_dst, fill.ctypes.data, b.dst_bytes) == 0
+        assert lib.infl_batch_dev_sorted(b.d_src, b.d_soff, b.d_dst, b.d_doff, 1, n, b.d_status, b.d_outlen, work, None) == 0
+        dst, status, outlen, _ = b.results()
+    finally:
+        lib.infl_gpu_free(work)
+        b.free()
+    assert np.array_equal(status, want_status) and np.array_equal(outlen, want_outlen)
+    assert np.array_equal(status0, want_status) and np.array_equal(outlen0, want_outlen)
+    for i in range(n):
+        a, m = int(dst_off[i]), int(outlen[i])
+        assert np.array_equal(dst[a:a + m], want_dst[a:a + m]), i
+    assert (status != 0).sum() > 0 or n == 1
