@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <type_traits>
 
 #include "infl_device.h"
 
@@ -1469,7 +1470,7 @@ __device__ __forceinline__ void pl_step(ParLane &r, const ParCtx &c, uint32_t &v
     const uint32_t cl    = (e >> 5) & 15u;
     const uint32_t extra = __builtin_amdgcn_ubfe(b, cl, (e & 31u) - cl);   // (a literal: not used)
     const uint32_t mant  = (((e >> 9) & 7u) << ((e & 31u) - cl)) + extra;
-    const uint32_t len   = (e & F::F_L258) ? 258u : 3u + mant;
+    const uint32_t len   = 3u + mant + 255u * ((e >> 12) & 1u);   // ("length 258": mantissa and extra bits are 0)
     r.o += tomatch ? len : (e >> 14) & 1u;                   // a distance entry adds nothing
     if (MODE == 2) value = isd ? mant : (e >> 5) & 0xffu;    // unused after a length code
   }
@@ -1499,33 +1500,44 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
   ParLane  r;
   uint32_t it = 0, ck[3] = {0u, 0u, 0u};
   int      nq = 0;
-  bool     all_done = false;
   pl_init(r, c, start, 0, limit, enable);
-  for (int q = 0; q < 4 && !all_done; q++) {
-    for (uint32_t k = 0; k < quarter || q == 3; k++) {
-      const bool more = r.p < r.lim;
-      if (!__ballot(more)) {
-        all_done = true;
-        break;
-      }
-      if (more) {
+  if constexpr (!FULL) {                             // positions only: no checkpoints, one plain loop
+    while (__ballot(r.p < r.lim)) {
+      if (r.p < r.lim) {
         uint32_t value;
-        pl_step<FULL ? 1 : 0>(r, c, value);
+        pl_step<0>(r, c, value);
       }
       it++;
     }
-    if (FULL && q < 3 && !all_done) {
-      if (__ballot(pl_in_match(r))) {                // lanes inside a match finish it first
-        if (pl_in_match(r)) {
-          uint32_t value;
-          pl_step<1>(r, c, value);
-        }
+  }
+  if constexpr (FULL) {
+    // one loop; every `quarter` steps (three times) all lanes note a checkpoint
+    uint32_t left = quarter;
+    for (;;) {
+      const bool more = r.p < r.lim;
+      if (!__ballot(more)) break;
+      if (more) {
+        uint32_t value;
+        pl_step<1>(r, c, value);
       }
-      ck[q] = ((pl_pos(r, c) - round0) << 12) | r.o;
-      nq    = q + 1;
-      if (!pl_in_match(r) && r.o >= PAR_LANE_CAP && r.p < r.lim) {   // byte cap: the round ends with this lane
-        r.st  = 3;
-        r.lim = 0;
+      it++;
+      if (nq < 3 && --left == 0) {
+        if (__ballot(pl_in_match(r))) {              // lanes inside a match finish it first
+          if (pl_in_match(r)) {
+            uint32_t value;
+            pl_step<1>(r, c, value);
+          }
+        }
+        const uint32_t state = ((pl_pos(r, c) - round0) << 12) | r.o;
+        ck[0] = nq == 0 ? state : ck[0];
+        ck[1] = nq == 1 ? state : ck[1];
+        ck[2] = nq == 2 ? state : ck[2];
+        nq++;
+        left = quarter;
+        if (!pl_in_match(r) && r.o >= PAR_LANE_CAP && r.p < r.lim) {   // byte cap: the round ends with this lane
+          r.st  = 3;
+          r.lim = 0;
+        }
       }
     }
   }
@@ -1772,26 +1784,36 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
         cq.column = chl;
         cq.colbit = inbyte * 8u + chl * PAR_S;
         group_sync();
-        pl_init(rl, cq, act ? pb : B + chl * PAR_S, q ? kb & 0xfffu : 0u, act ? pe : B + chl * PAR_S, act);
-        while (__ballot(rl.p < rl.lim)) {
-          if (rl.p < rl.lim) {
-            uint32_t       value;
-            const uint32_t at  = o0 + rl.o;
-            const bool     isd = pl_in_match(rl);
-            pl_step<2>(rl, cq, value);
-            // one store serves both kinds of head: a literal at its own byte, a match (once its
-            // distance is known) at the byte the length code stood for; a length code stores nothing
-            const uint32_t where = isd ? oh : at;
-            const uint32_t head  = (isd ? LK_EXT : LK_LIT) | value;
-            const uint32_t dist  = isd ? value + 1u : 0u;
-            if (rl.lim == rl.limit) P.link[where] = (uint16_t)head;
-            oh = pl_in_match(rl) ? at : oh;
-            if (dist > pos + where) {                // distance reaches before the output start
-              bad    = true;
-              rl.lim = 0;
+        // (the lane counts in entries of the link buffer: its chain's offset in the group is in rl.o from the start)
+        pl_init(rl, cq, act ? pb : B + chl * PAR_S, o0 + (q ? kb & 0xfffu : 0u), act ? pe : B + chl * PAR_S, act);
+        // A distance that reaches before the start of the output can only occur within the first 32 KiB of output:
+        // behind them the walk runs without the test (two copies of the loop, chosen once per group).
+        auto walk = [&](auto near_start) {
+          while (__ballot(rl.p < rl.lim)) {
+            if (rl.p < rl.lim) {
+              uint32_t       value;
+              const uint32_t at  = rl.o;
+              const bool     isd = pl_in_match(rl);
+              pl_step<2>(rl, cq, value);
+              // one store serves both kinds of head: a literal at its own byte, a match (once its
+              // distance is known) at the byte the length code stood for, which is where the step
+              // before this one began; a length code stores nothing
+              const uint32_t where = isd ? oh : at;
+              const uint32_t head  = (isd ? LK_EXT : LK_LIT) | value;
+              if (rl.lim == rl.limit) P.link[where] = (uint16_t)head;
+              oh = at;
+              if constexpr (decltype(near_start)::value) {
+                const uint32_t dist = isd ? value + 1u : 0u;
+                if (dist > pos + where) {            // distance reaches before the output start
+                  bad    = true;
+                  rl.lim = 0;
+                }
+              }
             }
           }
-        }
+        };
+        if (pos < 32768u) walk(std::true_type{});
+        else walk(std::false_type{});
       }
       if (__ballot(bad)) {                           // (nothing of this group has been written yet)
         if constexpr (NOTE) {
