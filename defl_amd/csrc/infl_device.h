@@ -58,8 +58,12 @@ typedef struct InflResume {
   uint64_t bit, block_bit;
   uint32_t pos, flags;
   int32_t  detail;              /* INFL_D_* of the last call */
-  uint32_t reserved;
+  uint32_t reserved;            /* the output position before the last call */
+  uint64_t tables_bit;          /* 1 + bit position of the block header whose decode tables the call left in its
+                                   table buffer (0 = none) */
 } InflResume;
+/* size of the table buffer of infl_launch_resume: both decode tables in the reference's geometry */
+#define INFL_RESUME_TABLE_BYTES ((2048u + 512u) * 4u)
 
 /* Enqueues the one-stream incremental decode: src[0 .. srclen) is all the input seen so far,
    dst[0 .. cap) the output so far and the room behind it, *state (device memory) where the last
@@ -67,10 +71,12 @@ typedef struct InflResume {
    holding input bytes fresh_at .. srclen, which the kernel moves into src first.  hout / hstate
    (may be NULL): host memory the device can write; the call's new output bytes (at most hout_cap)
    and a copy of the state go there.  The state's `reserved` word is the output position before
-   the call.  0 or -1. */
+   the call.  tables (may be NULL): INFL_RESUME_TABLE_BYTES of device memory that belong to the
+   stream; a call that stops inside a Huffman block leaves the block's decode tables there and the
+   next call takes them up instead of building them again from the block's header.  0 or -1. */
 int infl_launch_resume(void *src, uint32_t srclen, void *dst, uint32_t cap, int zlib,
                        InflResume *state, const void *fresh, uint32_t fresh_at, void *hout,
-                       uint32_t hout_cap, InflResume *hstate, void *stream);
+                       uint32_t hout_cap, InflResume *hstate, void *tables, void *stream);
 
 /* Enqueues the batch kernel; all pointers are device pointers; `detail` (why a
    stream stopped) and `inpos` (input bytes consumed) may be NULL.  lanes =

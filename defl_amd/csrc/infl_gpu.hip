@@ -529,6 +529,7 @@ struct StreamCtx {
   void       *d_src = nullptr, *d_dst = nullptr;
   size_t      src_cap = 0, src_up = 0, dst_cap = 0;
   InflResume *d_state = nullptr;
+  void       *d_tables = nullptr;         // the decode tables of the block the last call stopped in
   uint8_t    *pin = nullptr;              // [InflResume | pad to 64][kStageIn input][kStageOut output]
   int         dev = 0;
 };
@@ -539,6 +540,7 @@ void infl_rt_stream_free(void *ctx) {
   if (c->d_src) (void)hipFree(c->d_src);
   if (c->d_dst) (void)hipFree(c->d_dst);
   if (c->d_state) (void)hipFree(c->d_state);
+  if (c->d_tables) (void)hipFree(c->d_tables);
   if (c->pin) (void)hipHostFree(c->pin);
   delete c;
 }
@@ -559,6 +561,7 @@ int infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst,
     if (!c) return -12;
     c->dev = dev;
     if (hipMalloc((void **)&c->d_state, sizeof(InflResume)) != hipSuccess ||
+        hipMalloc(&c->d_tables, INFL_RESUME_TABLE_BYTES) != hipSuccess ||
         hipMemsetAsync(c->d_state, 0, sizeof(InflResume), st) != hipSuccess ||
         hipHostMalloc((void **)&c->pin, 64 + kStageIn + kStageOut, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
@@ -612,7 +615,7 @@ int infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst,
   }
   c->src_up = acc_len;
   ok = ok && infl_launch_resume(c->d_src, (uint32_t)acc_len, c->d_dst, dstlen, zlib ? 1 : 0, c->d_state, fresh,
-                                (uint32_t)fresh_at, hout, (uint32_t)kStageOut, hstate, st) == 0;
+                                (uint32_t)fresh_at, hout, (uint32_t)kStageOut, hstate, c->d_tables, st) == 0;
   ok = ok && hipStreamSynchronize(st) == hipSuccess;
   if (ok) {
     *out = *hstate;

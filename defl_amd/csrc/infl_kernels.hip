@@ -2466,13 +2466,23 @@ __global__ __launch_bounds__(64, 1) void infl_resume_kernel(uint8_t *src, uint32
                                                              InflResume *__restrict__ state,
                                                              const uint8_t *__restrict__ fresh, uint32_t fresh_at,
                                                              uint8_t *__restrict__ hout, uint32_t hout_cap,
-                                                             InflResume *__restrict__ hstate) {
+                                                             InflResume *__restrict__ hstate,
+                                                             uint4 *__restrict__ tables) {
   typedef RefFmt F;
   static_assert(T == 64, "one wavefront decodes the stream");
-  __shared__ StreamLds<F> L;
+  static_assert(offsetof(StreamLds<F>, dist) == sizeof(F::entry_t) * F::LIT_CAP &&
+                    sizeof(F::entry_t) * (F::LIT_CAP + F::DIST_CAP) == INFL_RESUME_TABLE_BYTES,
+                "the two tables lie one behind the other at the start of the working set");
+  __shared__ __attribute__((aligned(16))) StreamLds<F> L;
+  constexpr uint32_t TABLE_VEC = INFL_RESUME_TABLE_BYTES / 16u;
   const int lig = threadIdx.x;
   uint64_t  bit = state->bit, block_bit = state->block_bit;
   uint32_t  pos = state->pos, flags = state->flags;
+  // Byte-wise feeding means a call per symbol or less: building the block's tables again from its header at every
+  // call (tens of microseconds) was most of a call.  The tables of the block a call stops in stay in the stream's
+  // table buffer; the call that resumes in that block loads them (10 KiB, coalesced).
+  uint64_t  tables_bit = tables ? state->tables_bit : 0;
+  bool      tables_fresh = false;                    // built by this call for the block in hand
   const uint32_t pos_before = pos;
   if (fresh && fresh_at < srclen)
     for (uint32_t k = (uint32_t)lig; k < srclen - fresh_at; k += T) src[fresh_at + k] = fresh[k];
@@ -2519,12 +2529,19 @@ __global__ __launch_bounds__(64, 1) void infl_resume_kernel(uint8_t *src, uint32
       if (bfinal) flags |= INFL_RS_DONE;
       continue;
     }
-    int b;
-    if (btype == 1) {
-      const int f = setup_fixed<T, F>(L, lig, 0);
-      b = f == BUILD_OK ? INFL_D_OK : INFL_D_INTERNAL;
+    int b = INFL_D_OK;
+    if ((flags & INFL_RS_INBLOCK) && tables_bit == block_bit + 1u) {   // the tables the last call left
+      uint4 *lv = (uint4 *)&L;
+      for (uint32_t k = (uint32_t)lig; k < TABLE_VEC; k += T) lv[k] = tables[k];
+      group_sync();
     } else {
-      b = setup_dynamic<T, F>(r, L, lig, 0);
+      if (btype == 1) {
+        const int f = setup_fixed<T, F>(L, lig, 0);
+        b = f == BUILD_OK ? INFL_D_OK : INFL_D_INTERNAL;
+      } else {
+        b = setup_dynamic<T, F>(r, L, lig, 0);
+      }
+      tables_fresh = b == INFL_D_OK;
     }
     if (b != INFL_D_OK) {
       rc = b == INFL_D_NOFIT ? INFL_D_INTERNAL : b;
@@ -2540,10 +2557,16 @@ __global__ __launch_bounds__(64, 1) void infl_resume_kernel(uint8_t *src, uint32
     }
     bit = block_bit = rd_bitpos(r, src);
     flags &= ~INFL_RS_INBLOCK;
+    tables_fresh = false;
     if (bfinal) flags |= INFL_RS_DONE;
   }
   if (rc != INFL_D_OK && !(flags & INFL_RS_INBLOCK)) bit = block_bit;
   group_sync();
+  if (tables && (flags & INFL_RS_INBLOCK) && tables_fresh) {   // the block goes on in the next call: keep its tables
+    const uint4 *lv = (const uint4 *)&L;
+    for (uint32_t k = (uint32_t)lig; k < TABLE_VEC; k += T) tables[k] = lv[k];
+    tables_bit = block_bit + 1u;
+  }
   if (hout) {
     const uint32_t fresh_out = pos - pos_before < hout_cap ? pos - pos_before : hout_cap;
     for (uint32_t k = (uint32_t)lig; k < fresh_out; k += T) hout[k] = dst[pos_before + k];
@@ -2556,6 +2579,7 @@ __global__ __launch_bounds__(64, 1) void infl_resume_kernel(uint8_t *src, uint32
     ns.flags     = flags;
     ns.detail    = rc;
     ns.reserved  = pos_before;                       // where this call's output begins
+    ns.tables_bit = tables_bit;
     *state = ns;
     if (hstate) *hstate = ns;
   }
@@ -3353,11 +3377,11 @@ extern "C" int infl_launch_checked(const void *src, const uint64_t *src_off, voi
 
 extern "C" int infl_launch_resume(void *src, uint32_t srclen, void *dst, uint32_t cap, int zlib,
                                   InflResume *state, const void *fresh, uint32_t fresh_at, void *hout,
-                                  uint32_t hout_cap, InflResume *hstate, void *stream) {
+                                  uint32_t hout_cap, InflResume *hstate, void *tables, void *stream) {
   DEFL_LAUNCH_GROUP(64);
   hipLaunchKernelGGL((defl::infl_resume_kernel<64>), dim3(1), dim3(64), 0, (hipStream_t)stream, (uint8_t *)src,
                      srclen, (uint8_t *)dst, cap, zlib, state, (const uint8_t *)fresh, fresh_at, (uint8_t *)hout,
-                     hout_cap, hstate);
+                     hout_cap, hstate, (uint4 *)tables);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -228,6 +228,8 @@ static int main_resume(int argc, char **argv) {
     InflResume st;
     memset(&st, 0, sizeof(st));
     uint8_t *out = (uint8_t *)calloc(1, cap ? cap : 1);
+    void *tables = nullptr;                      // the stream's table buffer (exact size; every other stream runs without one)
+    if (!(i & 1) && posix_memalign(&tables, 16, INFL_RESUME_TABLE_BYTES) != 0) return 2;
     uint64_t fed = 0;
     do {
       // the arena holds what earlier calls brought; this call's bytes come through `fresh`, its new output bytes
@@ -242,7 +244,7 @@ static int main_resume(int argc, char **argv) {
       memcpy(in, src.data() + so[i], before);
       memcpy(fresh, src.data() + so[i] + before, fed - before);
       if (infl_launch_resume(in, (uint32_t)fed, out, (uint32_t)cap, flags & 1, &st, fresh, (uint32_t)before, hout,
-                             (uint32_t)sizeof(hout), &hst, nullptr) != 0) return 3;
+                             (uint32_t)sizeof(hout), &hst, tables, nullptr) != 0) return 3;
       free(in);
       free(fresh);
       if (memcmp(&hst, &st, sizeof(st)) != 0 || st.reserved > st.pos) return 4;
@@ -254,6 +256,7 @@ static int main_resume(int argc, char **argv) {
     outlen[i] = st.pos;
     memcpy(dst.data() + dof[i], out, st.pos < cap ? st.pos : cap);
     free(out);
+    free(tables);
   }
   f = fopen(argv[2], "wb");
   fwrite(status.data(), 4, n, f);
