@@ -1315,6 +1315,9 @@ constexpr int PAR_G    = PAR_S / 32;
 constexpr int PAR_ROWS = PAR_G + 4;
 static_assert((PAR_G & (PAR_G - 1)) == 0 && PAR_G >= 4, "sub-sequence length is a power of two >= 128");
 
+#ifndef DEFL_PAR_FETCH_BATCHES
+#define DEFL_PAR_FETCH_BATCHES 4                     // of 256 output bytes: 16 byte fetches per lane in flight in the write-out
+#endif
 #ifndef DEFL_PAR_PAD
 #define DEFL_PAR_PAD 0                               // experiments: extra LDS per wave (lowers occupancy)
 #endif
@@ -1900,34 +1903,47 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
       //     the stores and most of the loads of bytes from before the group coalesce).  All loads
       //     first, the bytes parked four to a register, then all stores: loads and stores share
       //     one in-order counter, so a load behind a store would wait for the store to complete.
+      //     The fetches of DEFL_PAR_FETCH_BATCHES batches are issued together, in straight-line code
+      //     (a branch per batch makes one memory round trip per batch; registers limit the number).
       {
         constexpr int NB = PAR_R / 256;
+        constexpr int HB = DEFL_PAR_FETCH_BATCHES;   // batches whose fetches are in flight together
         uint32_t      pk[NB];
 #pragma unroll
-        for (int bt = 0; bt < NB; bt++) {
-          pk[bt] = 0;
-          if ((uint32_t)bt * 256u < total_out) {     // four consecutive bytes per lane
-            uint64_t q;
-            __builtin_memcpy(&q, &P.link[bt * 256 + 4 * lane], 8);
-            uint32_t g[4];
+        for (int h = 0; h < NB; h += HB) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const uint32_t v    = (uint32_t)(q >> (16 * k)) & 0xffffu;
+          for (int j = 0; j < HB; j++) pk[h + j] = 0;
+          if ((uint32_t)h * 256u < total_out) {      // (wave-uniform)
+            uint64_t q[HB];
+            uint32_t g[HB][4];
+#pragma unroll
+            for (int j = 0; j < HB; j++) {           // four consecutive bytes per lane and batch
+              __builtin_memcpy(&q[j], &P.link[(h + j) * 256 + 4 * lane], 8);
+              // a batch behind the group's end holds what an earlier group left there: it fetches like literals
+              if ((uint32_t)(h + j) * 256u >= total_out) q[j] = 0;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const uint32_t v    = (uint32_t)(q[j] >> (16 * k)) & 0xffffu;
 #if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 1     // (diagnostic, wrong output: every fetch hits the line before the group)
-              const uint32_t back = pos ? 1u : 0u;
+                const uint32_t back = pos ? 1u : 0u;
 #else
-              const uint32_t back = v >= LK_EXT ? v - (LK_EXT - 1u) : (pos ? 1u : 0u);
+                const uint32_t back = v >= LK_EXT ? v - (LK_EXT - 1u) : (pos ? 1u : 0u);
 #endif
 #if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 2     // (diagnostic, wrong output: no fetch at all)
-              g[k] = back;
+                g[j][k] = back;
 #else
-              g[k] = dst[pos - back];
+                g[j][k] = dst[pos - back];
 #endif
+              }
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const uint32_t v = (uint32_t)(q >> (16 * k)) & 0xffffu;
-              pk[bt] |= ((v >= LK_EXT ? g[k] : v) & 0xffu) << (8 * k);
+            for (int j = 0; j < HB; j++) {
+              const uint64_t qq = q[j];
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const uint32_t v = (uint32_t)(qq >> (16 * k)) & 0xffffu;
+                pk[h + j] |= ((v >= LK_EXT ? g[j][k] : v) & 0xffu) << (8 * k);
+              }
             }
           }
         }

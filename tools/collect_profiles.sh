@@ -18,6 +18,9 @@ bash tools/pmc_run.sh ${tag}_pmc > ${o}_pmc.out 2>&1 &&
 echo "[collect] png" &&
 timeout -k 10 200 python3 -u tools/png_bench.py > ${o}_png_bench.json 2> ${o}_png_bench.err &&
 bash tools/pmc_run.sh ${tag}_pngpmc tools/png_bench.py --reps 2 > ${o}_pngpmc.out 2>&1 &&
+echo "[collect] phase cycles" &&
+DEFL_AMD_LIB=$PWD/defl_amd/libdefl_amd_prof.so timeout -k 10 200 python3 -u tools/par_profile.py > ${o}_phase_cycles.txt 2> ${o}_phase_cycles.err &&
+DEFL_AMD_LIB=$PWD/defl_amd/libdefl_amd_prof.so timeout -k 10 200 python3 -u tools/par_profile.py --size 1024 --streams 65536 > ${o}_phase_cycles_1k.txt 2>> ${o}_phase_cycles.err &&
 echo "[collect] ubench" &&
 timeout -k 10 200 tools/ubench/ubench > ${o}_ubench.txt 2>&1 &&
 echo "[collect] done"

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collects the PMC passes of the headline bench (one rocprofv3 run per pass) and prints the means per kernel.
 #   tools/pmc_run.sh <tag> [python script and arguments]      (on the GPU box, from the repository root)
-# Without a script: bench.py --steps 2 --warmup 1 --no-cpu-baseline.
+# Without a script: bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary.
 set -u
 tag=${1:-pmc}
 shift
-if [ $# -eq 0 ]; then set -- bench.py --steps 2 --warmup 1 --no-cpu-baseline; fi
+if [ $# -eq 0 ]; then set -- bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary; fi
 prog=("$@")
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
