@@ -1923,11 +1923,14 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
               if ((uint32_t)(h + j) * 256u >= total_out) q[j] = 0;
 #pragma unroll
               for (int k = 0; k < 4; k++) {
+                // a resolved match byte is LK_EXT | (how far before the group - 1); a literal fetches the stream's
+                // first byte (the subtraction wraps for it and the minimum brings it back: no select)
                 const uint32_t v    = (uint32_t)(q[j] >> (16 * k)) & 0xffffu;
 #if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 1     // (diagnostic, wrong output: every fetch hits the line before the group)
                 const uint32_t back = pos ? 1u : 0u;
 #else
-                const uint32_t back = v >= LK_EXT ? v - (LK_EXT - 1u) : (pos ? 1u : 0u);
+                const uint32_t far  = v - (LK_EXT - 1u);
+                const uint32_t back = far < pos ? far : pos;
 #endif
 #if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 2     // (diagnostic, wrong output: no fetch at all)
                 g[j][k] = back;
@@ -1937,13 +1940,12 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
               }
             }
 #pragma unroll
-            for (int j = 0; j < HB; j++) {
-              const uint64_t qq = q[j];
-#pragma unroll
-              for (int k = 0; k < 4; k++) {
-                const uint32_t v = (uint32_t)(qq >> (16 * k)) & 0xffffu;
-                pk[h + j] |= ((v >= LK_EXT ? g[j][k] : v) & 0xffu) << (8 * k);
-              }
+            for (int j = 0; j < HB; j++) {           // four bytes at a time: literals and fetched bytes, merged under a byte mask
+              const uint32_t qx = (uint32_t)q[j], qy = (uint32_t)(q[j] >> 32);
+              const uint32_t lit4  = __builtin_amdgcn_perm(qy, qx, 0x06040200u);
+              const uint32_t ext4  = __builtin_amdgcn_perm(pk_sign16(qy), pk_sign16(qx), 0x06040200u);
+              const uint32_t got4  = g[j][0] | (g[j][1] << 8) | (g[j][2] << 16) | (g[j][3] << 24);
+              pk[h + j] = (got4 & ext4) | (lit4 & ~ext4);
             }
           }
         }
