@@ -1949,8 +1949,19 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
             }
           }
         }
+#if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 3     // (diagnostic, wrong output: one store per lane and group instead of eight)
+        {
+          uint32_t x = 0;
+#pragma unroll
+          for (int bt = 0; bt < NB; bt++) x ^= pk[bt];
+          if (4u * (uint32_t)lane + 4u <= total_out) __builtin_memcpy(dst + pos + 4 * lane, &x, 4);
+        }
+#pragma unroll
+        for (int bt = NB; bt < NB; bt++) {
+#else
 #pragma unroll
         for (int bt = 0; bt < NB; bt++) {
+#endif
           const uint32_t i = (uint32_t)(bt * 256 + 4 * lane);
           if (i + 4u <= total_out) {
             __builtin_memcpy(dst + pos + i, &pk[bt], 4);
