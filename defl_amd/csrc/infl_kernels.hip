@@ -1351,7 +1351,7 @@ struct alignas(16) ParLds {
 
 struct ParCtx {
   const uint32_t *in;            // staged words (ParLds::in)
-  uint32_t        column;        // the lane's column there (row stride 64)
+  uint32_t        column;        // the lane's column there (row stride 64), as a byte offset: 4 * column
   uint32_t        colbit;        // bit position of the column's first word
   uint32_t        total_bits;    // stream length in bits
   const uint16_t *lit, *dist;
@@ -1384,6 +1384,15 @@ __device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t srclane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(srclane << 2), (int)v);
 }
 
+// The value as it is, with its range hidden from the compiler: an OR of bit fields that it can prove disjoint
+// becomes an addition, which then misses the and-or instruction.
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+#if defined(__clang__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
 // Two 16-bit values to a register, worked on with the packed integer instructions (v_pk_sub_u16, v_pk_ashrrev_i16);
 // a portable form serves compilers without vector extensions (the host-side emulation of the test suite).
 #if defined(__clang__)
@@ -1407,8 +1416,9 @@ __device__ __forceinline__ uint32_t pk_sign16(uint32_t a) {
 // 32 bits of the stream from bit `rel` of the column on (see ParLds)
 __device__ __forceinline__ uint32_t par_peek(const ParCtx &c, uint32_t rel) {
   static_assert(PAR_ROWS <= 16, "the row index is masked to four bits");
-  const uint32_t k = (((rel >> 5) & 15u) << 6) | c.column;   // row : column (bit field + shift-or)
-  return __builtin_amdgcn_alignbit(c.in[k + 64u], c.in[k], rel);
+  const uint32_t  at = ((rel << 3) & 0xf00u) | c.column;   // byte offset of row : column (shift, and-or)
+  const uint32_t *w  = (const uint32_t *)((const char *)c.in + at);
+  return __builtin_amdgcn_alignbit(w[64], w[0], rel);
 }
 
 // Per-lane decoder state.  One step decodes ONE code: a literal/length code or, after a length
@@ -1473,7 +1483,8 @@ __device__ __forceinline__ void pl_step(ParLane &r, const ParCtx &c, uint32_t &v
     const uint32_t cl    = (e >> 5) & 15u;
     const uint32_t extra = __builtin_amdgcn_ubfe(b, cl, (e & 31u) - cl);   // (a literal: not used)
     const uint32_t mant  = (((e >> 9) & 7u) << ((e & 31u) - cl)) + extra;
-    const uint32_t len   = 3u + mant + 255u * ((e >> 12) & 1u);   // ("length 258": mantissa and extra bits are 0)
+    const uint32_t len   = 3u + mant + (uint32_t)__umul24(255u, opaque((e >> 12) & 1u));   // ("length 258": mantissa and extra bits are 0;
+                                                                           //  a multiply-add, not a compare and a select)
     r.o += tomatch ? len : (e >> 14) & 1u;                   // a distance entry adds nothing
     if (MODE == 2) value = isd ? mant : (e >> 5) & 0xffu;    // unused after a length code
   }
@@ -1504,14 +1515,14 @@ __device__ __forceinline__ uint32_t par_scan(const ParCtx &c, bool enable, uint3
   uint32_t it = 0, ck[3] = {0u, 0u, 0u};
   int      nq = 0;
   pl_init(r, c, start, 0, limit, enable);
-  if constexpr (!FULL) {                             // positions only: no checkpoints, one plain loop
-    while (__ballot(r.p < r.lim)) {
+  if constexpr (!FULL) {                             // positions only: no checkpoints, one plain loop (tested at its end:
+    do {                                             // the compiler then keeps no copies of the lane's state around it)
       if (r.p < r.lim) {
         uint32_t value;
         pl_step<0>(r, c, value);
       }
       it++;
-    }
+    } while (__ballot(r.p < r.lim));
   }
   if constexpr (FULL) {
     // one loop; every `quarter` steps (three times) all lanes note a checkpoint
@@ -1659,7 +1670,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
     PROF_MARK(0);
     ParCtx c;
     c.in         = P.in;
-    c.column     = (uint32_t)lane & 63u;            // (spelling out the range lets the address be an OR)
+    c.column     = opaque(((uint32_t)lane & 63u) << 2);   // (its place in the address stays an OR: and-or)
     c.colbit     = inbyte * 8u + (uint32_t)lane * PAR_S;
     c.total_bits = total_bits;
     c.lit        = lit;
@@ -1784,7 +1795,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
         ParCtx   cq  = c;                            // the chain's column instead of the lane's own
         uint32_t oh  = 0;
         bool     act = ch < a + nch && pb < pe;
-        cq.column = chl;
+        cq.column = opaque(chl << 2);
         cq.colbit = inbyte * 8u + chl * PAR_S;
         group_sync();
         // (the lane counts in entries of the link buffer: its chain's offset in the group is in rl.o from the start)
@@ -1792,7 +1803,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
         // A distance that reaches before the start of the output can only occur within the first 32 KiB of output:
         // behind them the walk runs without the test (two copies of the loop, chosen once per group).
         auto walk = [&](auto near_start) {
-          while (__ballot(rl.p < rl.lim)) {
+          do {                                       // (tested at the end: no copies of the lane's state around the loop)
             if (rl.p < rl.lim) {
               uint32_t       value;
               const uint32_t at  = rl.o;
@@ -1813,7 +1824,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
                 }
               }
             }
-          }
+          } while (__ballot(rl.p < rl.lim));
         };
         if (pos < 32768u) walk(std::true_type{});
         else walk(std::false_type{});

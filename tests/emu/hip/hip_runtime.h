@@ -130,6 +130,9 @@ static inline uint32_t __builtin_amdgcn_ubfe(uint32_t v, uint32_t off, uint32_t 
 static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (s & 3u)));
 }
+// v_mul_u32_u24: the product of the low 24 bits of both operands
+static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+
 // v_perm_b32: every selector byte picks one of the 8 bytes of s0:s1 (0-3 from s1, 4-7 from s0); 12 gives 0x00,
 // above 12 gives 0xff, 8-11 replicate a sign bit (not used by the kernel)
 static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
