@@ -16,7 +16,11 @@ HIP_STREAM_CAPTURE_MODE_RELAXED = 2
 
 
 def _hip():
-    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")          # the runtime the engine itself is linked with
+    """The HIP runtime the engine is using in this process (the one of /opt/rocm, or the one that came with torch
+    when a test before this one imported torch first: both have the same soname, whichever is loaded first serves)."""
+    paths = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert len(paths) == 1, paths
+    hip = C.CDLL(paths.pop())
     for name, args in (("hipStreamCreate", [C.POINTER(C.c_void_p)]), ("hipStreamDestroy", [C.c_void_p]),
                        ("hipStreamSynchronize", [C.c_void_p]), ("hipStreamBeginCapture", [C.c_void_p, C.c_int]),
                        ("hipStreamEndCapture", [C.c_void_p, C.POINTER(C.c_void_p)]),
