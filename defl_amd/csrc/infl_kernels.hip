@@ -822,8 +822,8 @@ constexpr int INFL_D_NOFIT = 100;   // valid so far, but the tables exceed the c
 // same for all lanes, so it is kept in scalar registers and worked out by the scalar unit (the vector pipe is
 // what the decoder runs short of): the bit reservoir is refilled with v_readlane from the window, the 256-entry
 // code-length table sits in two vector registers per lane (four 16-bit entries) and is read with v_readlane, the
-// lengths go into five vector registers (lane l, register j = symbol l + 64 j) with v_writelane and from there
-// straight into the table builders.  Same rules and the same order of tests as setup_dynamic below.
+// lengths are collected in LDS and go from there into five vector registers (lane l, register j = symbol
+// l + 64 j) for the table builders.  Same rules and the same order of tests as setup_dynamic below.
 struct ScalarBits {
   uint64_t bits;
   uint32_t n, idx;       // idx: next word of the reader's window
@@ -921,7 +921,13 @@ __device__ __forceinline__ int setup_dynamic_wave_body(FastReader<64> &r, Stream
   const uint32_t t01 = (uint32_t)ctab[lane] | ((uint32_t)ctab[lane + 64] << 16);
   const uint32_t t23 = (uint32_t)ctab[lane + 128] | ((uint32_t)ctab[lane + 192] << 16);
 
-  uint32_t len[5] = {0, 0, 0, 0, 0};
+  // The lengths are collected in LDS (320 bytes where the distance table will be built later, zeroed first:
+  // a run of zeros is then only a step forward) and go to registers when the header is through.
+  uint8_t *lens = L.lens();
+  group_sync();
+  ((uint32_t *)lens)[lane] = 0;
+  if (lane < 16) ((uint32_t *)lens)[lane + 64] = 0;
+  group_sync();
   uint32_t prev = 0;
   for (uint32_t i = 0; i < n;) {
     sb_fill(b, r);
@@ -934,14 +940,7 @@ __device__ __forceinline__ int setup_dynamic_wave_body(FastReader<64> &r, Stream
     const uint32_t sym = e >> 8;
     sb_drop(b, e & 255u);
     if (sym < 16) {
-      const uint32_t at = i & 63u;
-      switch (i >> 6) {                              // scalar branches
-        case 0: len[0] = (uint32_t)lane == at ? sym : len[0]; break;
-        case 1: len[1] = (uint32_t)lane == at ? sym : len[1]; break;
-        case 2: len[2] = (uint32_t)lane == at ? sym : len[2]; break;
-        case 3: len[3] = (uint32_t)lane == at ? sym : len[3]; break;
-        default: len[4] = (uint32_t)lane == at ? sym : len[4]; break;
-      }
+      lens[i] = (uint8_t)sym;                        // (every lane stores the same byte to the same place)
       prev = sym;
       i++;
     } else {
@@ -953,18 +952,18 @@ __device__ __forceinline__ int setup_dynamic_wave_body(FastReader<64> &r, Stream
       sb_drop(b, xb);
       if (i + rep > n) return INFL_D_INVALID;
       if (sym == 16) {
-        if (prev) {
-#pragma unroll
-          for (int j = 0; j < 5; j++)
-            if ((i + rep - 1u) >> 6 >= (uint32_t)j && i >> 6 <= (uint32_t)j)       // scalar
-              len[j] = (uint32_t)lane + 64u * j - i < rep ? prev : len[j];
-        }
+        if (prev && (uint32_t)lane < rep) lens[i + (uint32_t)lane] = (uint8_t)prev;
       } else {
         prev = 0;
       }
       i += rep;
     }
   }
+  group_sync();
+  uint32_t len[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) len[j] = lens[lane + 64 * j];
+  group_sync();
   sb_close(b, r);
 
   int rc = build_table_wave<F, true>(L.lit, len[0], len[1], len[2], len[3], (uint32_t)lane + 256u < hlit ? len[4] : 0u, lane);
