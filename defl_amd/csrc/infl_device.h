@@ -153,6 +153,9 @@ int infl_rt_batch_host(const void *src, const uint64_t *src_off, void *dst,
 int  infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst, uint32_t dstlen,
                          uint32_t dstpos, int zlib, InflResume *out);
 void infl_rt_stream_free(void *ctx);
+/* The stream starts over with its input (infl_reset_pool): the context keeps its device buffers and the next step
+   begins at the first bit again. */
+void infl_rt_stream_restart(void *ctx);
 
 #ifdef __cplusplus
 }

@@ -532,6 +532,7 @@ struct StreamCtx {
   void       *d_tables = nullptr;         // the decode tables of the block the last call stopped in
   uint8_t    *pin = nullptr;              // [InflResume | pad to 64][kStageIn input][kStageOut output]
   int         dev = 0;
+  bool        restart = false;            // the next step begins the stream again (state cleared on the device first)
 };
 
 void infl_rt_stream_free(void *ctx) {
@@ -545,6 +546,13 @@ void infl_rt_stream_free(void *ctx) {
   delete c;
 }
 
+// Called by infl_reset_pool(): the buffers stay (a stream object that is reset for every input would otherwise pay
+// three device allocations and a pinned one per input); the state is cleared by the next step, on its stream.
+void infl_rt_stream_restart(void *ctx) {
+  StreamCtx *c = (StreamCtx *)ctx;
+  if (c) c->restart = true;
+}
+
 int infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst, uint32_t dstlen,
                         uint32_t dstpos, int zlib, InflResume *out) {
   if (!ctxp || !out || acc_len > 0xffffffffu) return -1;
@@ -555,7 +563,19 @@ int infl_rt_stream_step(void **ctxp, const void *acc, size_t acc_len, void *dst,
   hipStream_t st = aux_stream_on(dev);
   if (!st) return -1;
   StreamCtx *c = (StreamCtx *)*ctxp;
+  if (c && c->restart && c->dev != dev) {             // a fresh start on another GPU: nothing of the old context serves
+    infl_rt_stream_free(c);
+    *ctxp = c = nullptr;
+  }
   if (c && c->dev != dev) return -1;                  // a stream stays on the GPU it began on
+  if (c && c->restart) {
+    if (hipMemsetAsync(c->d_state, 0, sizeof(InflResume), st) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    c->src_up  = 0;
+    c->restart = false;
+  }
   if (!c) {
     c = new (std::nothrow) StreamCtx();
     if (!c) return -12;

@@ -172,10 +172,8 @@ infl_reset_pool(infl_stream_t * __restrict st) {
   st->mir_piece  = 0;
   st->mir_off    = 0;
   st->stream_started = 0;
-  if (st->sctx) {                                 /* the incremental decode starts over with the input */
-    infl_rt_stream_free(st->sctx);
-    st->sctx = NULL;
-  }
+  if (st->sctx)                                   /* the incremental decode starts over with the input */
+    infl_rt_stream_restart(st->sctx);
 }
 
 UNZ_EXPORT void
