@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--which", default="stored,fixed,mixed,runs,textruns,truncated,flushed,small,tiny,files,noisy,pngdev,gather,host,png")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--variant", type=int, default=-1, help="table variant (default: the library's)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per stream in the serial passes (default: the library's)")
     args = ap.parse_args()
     import torch  # noqa: F401  (same HIP runtime for the engine)
     from defl_amd import capi
@@ -85,6 +86,8 @@ def main():
     assert eng.lib.infl_gpu_init(0) == 0
     if args.variant >= 0:
         eng.lib.infl_gpu_set_table_variant(args.variant)
+    if args.lanes:
+        eng.lib.infl_gpu_set_lanes_per_stream(args.lanes)
     which = args.which.split(",")
     if "stored" in which:
         pairs = [wl.stored_stream(i, 65536) for i in range(256)]
