@@ -461,9 +461,17 @@ __device__ unsigned long long g_par_prof[32];   // diagnostic builds: cycle and 
 #ifdef DEFL_PAR_PROFILE_SETUP                    // split of the block set-up time (takes the slots of the scan histogram)
 #define SETUP_MARK(k) { if (T == 64) { const uint64_t t_ = __builtin_readcyclecounter(); if (lig == 0) atomicAdd(&g_par_prof[16 + (k)], (unsigned long long)(t_ - setup_t)); setup_t = t_; } }
 #define SETUP_DECL    uint64_t setup_t = __builtin_readcyclecounter()
+// (the wave path keeps its five intervals in registers and adds them up at its end: an atomic in the middle would be
+//  waited for at the next call boundary and land in the next interval)
+#define WSETUP_MARK(k) { const uint64_t t_ = __builtin_readcyclecounter(); setup_acc[k] = t_ - setup_t; setup_t = t_; }
+#define WSETUP_DECL    uint64_t setup_acc[5] = {0, 0, 0, 0, 0}
+#define WSETUP_FLUSH   { if (lane == 0) for (int k_ = 0; k_ < 5; k_++) atomicAdd(&g_par_prof[16 + k_], (unsigned long long)setup_acc[k_]); }
 #else
 #define SETUP_MARK(k)
 #define SETUP_DECL
+#define WSETUP_MARK(k)
+#define WSETUP_DECL
+#define WSETUP_FLUSH
 #endif
 
 
@@ -897,6 +905,8 @@ __device__ __forceinline__ int setup_dynamic_wave(FastReader<64> &r, StreamLds<F
 
 template <class F>
 __device__ __forceinline__ int setup_dynamic_wave_body(FastReader<64> &r, StreamLds<F> &L, int lane) {
+  SETUP_DECL;
+  WSETUP_DECL;
   ScalarBits b;
   sb_open(b, r);
   sb_fill(b, r);
@@ -916,7 +926,9 @@ __device__ __forceinline__ int setup_dynamic_wave_body(FastReader<64> &r, Stream
     sb_drop(b, 3);
   }
   uint16_t *ctab = L.ctab();
+  WSETUP_MARK(0);
   if (!build_clen_table<64>(ctab, packed, lane)) return INFL_D_INVALID;
+  WSETUP_MARK(1);
   // entries lane, lane + 64, lane + 128, lane + 192
   const uint32_t t01 = (uint32_t)ctab[lane] | ((uint32_t)ctab[lane + 64] << 16);
   const uint32_t t23 = (uint32_t)ctab[lane + 128] | ((uint32_t)ctab[lane + 192] << 16);
@@ -965,13 +977,17 @@ __device__ __forceinline__ int setup_dynamic_wave_body(FastReader<64> &r, Stream
   for (int j = 0; j < 5; j++) len[j] = lens[lane + 64 * j];
   group_sync();
   sb_close(b, r);
+  WSETUP_MARK(2);
 
   int rc = build_table_wave<F, true>(L.lit, len[0], len[1], len[2], len[3], (uint32_t)lane + 256u < hlit ? len[4] : 0u, lane);
+  WSETUP_MARK(3);
   if (rc == BUILD_OK) {
     // the distance lengths are symbols hlit .. hlit + hdist - 1, all in the fifth register: lane d takes symbol hlit + d
     const uint32_t dl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((hlit - 256u + (uint32_t)lane) & 63u) << 2), (int)len[4]);
     rc = build_table_wave<F, false>(L.dist, (uint32_t)lane < hdist ? dl : 0u, 0, 0, 0, 0, lane);
   }
+  WSETUP_MARK(4);
+  WSETUP_FLUSH;
   return rc == BUILD_OK ? INFL_D_OK : rc == BUILD_REJECT ? INFL_D_INVALID : INFL_D_NOFIT;
 }
 
