@@ -1771,13 +1771,25 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
 
     // The round's output is produced in groups of up to 16 consecutive chains whose bytes fit
     // the link buffer; four lanes share a chain (one quarter each) while the links are written.
+    // Where the bytes of the next 32 chains fit (data that compresses badly: few bytes to a chain), the
+    // group takes all of them with two lanes to a chain (one half each): as many trips through the emit
+    // loop for twice the chains, half as many groups.
     uint32_t a = 0;
     bool     stretched = false;
     while (a < nact) {
       const uint32_t base_cum = a ? wave_read(cum, a - 1u) : 0u;
-      const bool     fits     = (uint32_t)lane >= a && (uint32_t)lane < nact && (uint32_t)lane < a + 16u &&
+      const bool     fits     = (uint32_t)lane >= a && (uint32_t)lane < nact && (uint32_t)lane < a + 32u &&
                             cum - base_cum <= (uint32_t)PAR_R;
-      const uint32_t nch = (uint32_t)__popcll(__ballot(fits));
+      const uint32_t n32 = (uint32_t)__popcll(__ballot(fits)), rest = nact - a;
+#ifdef DEFL_PAR_NO_PAIRS                             // (experiments: always four lanes to a chain)
+      const bool two = false;
+#else
+#ifndef DEFL_PAR_PAIR_MIN
+#define DEFL_PAR_PAIR_MIN 32                         // chains that have to fit for a group of pairs (fewer: only at a round's end)
+#endif
+      const bool two = n32 > 16u && (n32 == (rest < 32u ? rest : 32u) || n32 >= (uint32_t)DEFL_PAR_PAIR_MIN);
+#endif
+      const uint32_t nch = two ? n32 : n32 < 16u ? n32 : 16u;
       if (nch == 0) {                                // a chain of more bytes than the link buffer takes
         if (!serial_stretch(wave_read(start, a))) return INFL_D_INVALID;
         stretched = true;
@@ -1797,15 +1809,17 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
       }
       bool bad = false;
       {
-        const uint32_t ch  = a + ((uint32_t)lane >> 2), q = (uint32_t)lane & 3u;
+        // the lane's stretch of its chain: quarters q .. qe - 1 (one quarter, or two where two lanes share a chain)
+        const uint32_t ch  = a + (two ? (uint32_t)lane >> 1 : (uint32_t)lane >> 2);
+        const uint32_t q   = two ? ((uint32_t)lane & 1u) << 1 : (uint32_t)lane & 3u, qe = two ? q + 2u : q + 1u;
         const uint32_t chl = ch < 64u ? ch : 63u;
         const uint32_t cs  = wave_read(start, chl), ce = wave_read(sc.exit, chl);
         const uint32_t o0  = wave_read(cum - sc.nout, chl) - base_cum;
         const uint32_t k1 = wave_read(sc.ck[0], chl), k2 = wave_read(sc.ck[1], chl), k3 = wave_read(sc.ck[2], chl);
-        const uint32_t kb = q == 1 ? k1 : q == 2 ? k2 : k3;      // state at the quarter's begin
-        const uint32_t ke = q == 0 ? k1 : q == 1 ? k2 : k3;      // and at its end
+        const uint32_t kb = q == 1 ? k1 : q == 2 ? k2 : k3;      // state at the stretch's begin
+        const uint32_t ke = qe == 1 ? k1 : qe == 2 ? k2 : k3;    // and at its end
         const uint32_t pb = q ? B + (kb >> 12) : cs;
-        const uint32_t pe = q < 3 ? B + (ke >> 12) : ce;
+        const uint32_t pe = qe < 4 ? B + (ke >> 12) : ce;
         ParLane  rl;
         ParCtx   cq  = c;                            // the chain's column instead of the lane's own
         uint32_t oh  = 0;
