@@ -1972,7 +1972,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
                 const uint32_t far  = v - (LK_EXT - 1u);
                 const uint32_t back = far < pos ? far : pos;
 #endif
-#if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 2     // (diagnostic, wrong output: no fetch at all)
+#if defined(DEFL_DIAG_WRITEOUT) && (DEFL_DIAG_WRITEOUT == 2 || DEFL_DIAG_WRITEOUT == 4)     // (diagnostic, wrong output: no fetch at all)
                 g[j][k] = back;
 #else
                 g[j][k] = dst[pos - back];
@@ -1989,12 +1989,12 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
             }
           }
         }
-#if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT == 3     // (diagnostic, wrong output: one store per lane and group instead of eight)
-        {
+#if defined(DEFL_DIAG_WRITEOUT) && DEFL_DIAG_WRITEOUT >= 3     // (diagnostic, wrong output: one store per lane and group instead of eight;
+        {                                                      //  4: no fetch either and a store only where the bytes happen to cancel)
           uint32_t x = 0;
 #pragma unroll
           for (int bt = 0; bt < NB; bt++) x ^= pk[bt];
-          if (4u * (uint32_t)lane + 4u <= total_out) __builtin_memcpy(dst + pos + 4 * lane, &x, 4);
+          if (4u * (uint32_t)lane + 4u <= total_out && (DEFL_DIAG_WRITEOUT == 3 || x == 0x12345678u)) __builtin_memcpy(dst + pos + 4 * lane, &x, 4);
         }
 #pragma unroll
         for (int bt = NB; bt < NB; bt++) {
