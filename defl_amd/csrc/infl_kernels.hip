@@ -1330,6 +1330,18 @@ constexpr int PAR_G    = PAR_S / 32;
 constexpr int PAR_ROWS = PAR_G + 4;
 static_assert((PAR_G & (PAR_G - 1)) == 0 && PAR_G >= 4, "sub-sequence length is a power of two >= 128");
 
+// Issue priority of the wavefront by phase (experiments; 0 and 0: no s_setprio at all)
+#ifndef DEFL_PAR_PRIO_STEPS
+#define DEFL_PAR_PRIO_STEPS 0
+#endif
+#ifndef DEFL_PAR_PRIO_BYTES
+#define DEFL_PAR_PRIO_BYTES 0
+#endif
+#if DEFL_PAR_PRIO_STEPS != DEFL_PAR_PRIO_BYTES
+#define PAR_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define PAR_PRIO(p)
+#endif
 #ifndef DEFL_PAR_FETCH_BATCHES
 #define DEFL_PAR_FETCH_BATCHES 4                     // of 256 output bytes: 16 byte fetches per lane in flight in the write-out
 #endif
@@ -1683,6 +1695,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
     }
     group_sync();
     PROF_MARK(0);
+    PAR_PRIO(DEFL_PAR_PRIO_STEPS);
     ParCtx c;
     c.in         = P.in;
     c.column     = opaque(((uint32_t)lane & 63u) << 2);   // (its place in the address stays an OR: and-or)
@@ -1870,6 +1883,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
       }
       group_sync();
       PROF_MARK(4);
+      PAR_PRIO(DEFL_PAR_PRIO_BYTES);
 
       // 5a. expand: every byte finds the head at or before it and becomes a literal, an index of an earlier
       //     byte of the group, or LK_EXT | how far before it.  A lane takes four consecutive entries of a
@@ -2014,6 +2028,7 @@ __device__ __forceinline__ int huffman_block_parallel(FastReader<64> &r, uint8_t
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       PROF_MARK(7);
+      PAR_PRIO(DEFL_PAR_PRIO_STEPS);
       pos += total_out;
       a += nch;
     }
